@@ -1,0 +1,124 @@
+"""
+Host-side descriptions of a task and a policy, and their conversion into the C structs of the ABI.
+These carry exactly the information that Pyrado's task / policy objects hold for the hot path:
+tasks -> Pyrado/pyrado/tasks/{desired_state,final_reward,reward_functions}.py,
+policies -> Pyrado/pyrado/policies/{linear,features,fnn}.py.
+"""
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi as abi
+
+REW_KINDS = dict(quadr=abi.REW_QUADR, exp=abi.REW_EXP_QUADR, scaledexp=abi.REW_SCALED_EXP_QUADR,
+                 swingup=abi.REW_SWINGUP)
+
+
+@dataclass
+class TaskSpec:
+    state_des: np.ndarray
+    rew_kind: str                       # 'quadr' | 'exp' | 'scaledexp' | 'swingup'
+    Q: Optional[np.ndarray] = None      # [S,S]
+    R: Optional[np.ndarray] = None      # [A,A]
+    radial_idcs: Optional[Sequence[int]] = None  # None -> DesStateTask
+    mod: Optional[Sequence[float]] = None        # modulation per radial index (default 2*pi)
+    final_mode: int = 0                 # FIN_* bits, 0 = no FinalRewTask
+    final_factor: float = 1e3
+    min_rew: float = 1e-4
+    swingup: Sequence[float] = (1.0, 0.2, 1e-3, 1.0, 0.1)
+    idx_x: int = 0
+    idx_th: int = 1
+
+    def to_c(self, S: int, A: int) -> abi.PshTask:
+        t = abi.PshTask()
+        t.rew_kind = REW_KINDS[self.rew_kind]
+        t.radial = 0 if self.radial_idcs is None else 1
+        mask = 0
+        for i in range(abi.PSH_MAX_STATE):
+            t.mod[i] = 2*np.pi
+        if self.radial_idcs is not None:
+            mods = self.mod if self.mod is not None else [2*np.pi]*len(self.radial_idcs)
+            for i, m in zip(self.radial_idcs, mods):
+                if not 0 <= int(i) < S:
+                    raise ValueError(f'radial index {i} outside the state of dimension {S}')
+                mask |= 1 << int(i)
+                t.mod[int(i)] = float(m)
+        t.radial_mask = mask
+        t.final_mode = int(self.final_mode)
+        t.idx_x, t.idx_th = int(self.idx_x), int(self.idx_th)
+        t.final_factor = float(self.final_factor)
+        t.min_rew = float(self.min_rew)
+        sd = np.asarray(self.state_des, dtype=np.float64).reshape(-1)
+        if sd.size != S:
+            raise ValueError(f'state_des has {sd.size} entries, the state has {S}')
+        for i in range(S):
+            t.state_des[i] = sd[i]
+        if self.rew_kind != 'swingup':
+            Q = np.asarray(self.Q, dtype=np.float64)
+            R = np.asarray(self.R, dtype=np.float64)
+            if Q.shape != (S, S) or R.shape != (A, A):
+                raise ValueError(f'Q must be {(S, S)} and R {(A, A)}, got {Q.shape} and {R.shape}')
+            for i, v in enumerate(Q.reshape(-1)):
+                t.Q[i] = v
+            for i, v in enumerate(R.reshape(-1)):
+                t.R[i] = v
+        for i, v in enumerate(self.swingup):
+            t.swingup[i] = float(v)
+        return t
+
+
+@dataclass
+class PolicySpec:
+    kind: str                                   # 'linear' | 'fnn'
+    obs_dim: int
+    act_dim: int
+    feats: Sequence[str] = field(default_factory=list)     # linear: feature names in FeatureStack order
+    hidden: Sequence[int] = field(default_factory=list)    # fnn: hidden sizes
+    hidden_nonlin: Sequence[Optional[str]] = field(default_factory=list)
+    out_nonlin: Optional[str] = None
+
+    @property
+    def num_feat(self) -> int:
+        return sum(1 if f == 'const' else self.obs_dim for f in self.feats)
+
+    @property
+    def num_param(self) -> int:
+        if self.kind == 'linear':
+            return self.act_dim*self.num_feat
+        n, last = 0, self.obs_dim
+        for h in self.hidden:
+            n += h*last + h
+            last = h
+        return n + self.act_dim*last + self.act_dim
+
+    def to_c(self, n_policies: int = 1, params_ptr: int = 0, index_ptr: int = 0) -> abi.PshPolicy:
+        p = abi.PshPolicy()
+        if self.kind == 'linear':
+            p.kind = abi.POL_LINEAR
+            if not 1 <= len(self.feats) <= abi.PSH_MAX_FEATS:
+                raise ValueError(f'a fused LinearPolicy takes 1..{abi.PSH_MAX_FEATS} feature functions')
+            p.n_feats = len(self.feats)
+            for i, f in enumerate(self.feats):
+                p.feats[i] = abi.FEAT_IDS[f]
+        elif self.kind == 'fnn':
+            p.kind = abi.POL_FNN
+            if not 1 <= len(self.hidden) <= abi.PSH_MAX_HIDDEN:
+                raise ValueError(f'a fused FNNPolicy takes 1..{abi.PSH_MAX_HIDDEN} hidden layers')
+            p.n_hidden = len(self.hidden)
+            nls = list(self.hidden_nonlin)
+            if len(nls) != len(self.hidden):
+                raise ValueError('one nonlinearity per hidden layer is required')
+            for i, (h, nl) in enumerate(zip(self.hidden, nls)):
+                if not 1 <= h <= abi.PSH_MAX_WIDTH:
+                    raise ValueError(f'hidden sizes must be within 1..{abi.PSH_MAX_WIDTH}')
+                p.hidden[i] = int(h)
+                p.hidden_nonlin[i] = abi.NL_IDS[nl]
+            p.out_nonlin = abi.NL_IDS[self.out_nonlin]
+        else:
+            raise ValueError(self.kind)
+        p.n_policies = int(n_policies)
+        p.num_param = self.num_param
+        p.params = params_ptr
+        p.policy_index = index_ptr
+        return p
