@@ -1,0 +1,825 @@
+// libpysimhip.so — kernels and C ABI (include/pysimhip.h) of the MI355X batched rollout engine.
+//
+// Kernels (all gfx950, wave64):
+//   k_rollout_linear<KIND, PER_ENV>  fused reset + T x (LinearPolicy forward, SimPyEnv.step); one lane per env
+//   k_rollout_fnn<KIND, HP>          same with an FNNPolicy: the hidden layers run on v_mfma_f64_16x16x4_f64 with
+//                                    the weights as the A operand and 16 environments as the columns of B, so a
+//                                    layer's accumulator is directly the next layer's B operand
+//   k_reset / k_step                 SimPyEnv.reset / SimPyEnv.step for caller-supplied actions
+//   k_randomize / k_sample_init      DomainRandomizer.randomize / init_space.sample_uniform with Philox4x32-10
+//   k_qbb_ik, k_segment_mean, k_pack_fnn
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "psh_env.h"
+#include "psh_rng.h"
+
+// ------------------------------------------------------------------------------------------------ context
+struct psh_ctx {
+    int device;
+    char err[512];
+    double* wfrag;       // packed FNN weights (fragment layout), grown on demand
+    size_t wfrag_doubles;
+    hipEvent_t ev0, ev1;
+    int timed;
+};
+
+static void set_err(psh_ctx* c, const char* fmt, const char* a = "", const char* b = "") {
+    if (c) snprintf(c->err, sizeof c->err, fmt, a, b);
+}
+
+#define PSH_HIP(ctx, call)                                                    \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            set_err(ctx, "%s failed: %s", #call, hipGetErrorString(e_));      \
+            return PSH_ERR_HIP;                                               \
+        }                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ kernel arguments
+struct RolloutArgs {
+    int n_envs, max_steps, flags, init_dim;
+    double dt;
+    const double* init_state; long ld_init;
+    const double* domain_param; const int* dp_index; long ld_dp;
+    psh_task task;
+    psh_policy pol;
+    int num_feat;          // LINEAR: total feature count F
+    int lds_doubles;       // FNN: doubles of the packed weight image
+    const double* wfrag;   // FNN: packed weight image (device)
+    double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
+};
+
+// ------------------------------------------------------------------------------------------------ math helpers
+PSH_DEV double nl_apply(int nl, double v) {
+    switch (nl) {
+    case PSH_NL_TANH: return tanh(v);
+    case PSH_NL_RELU: return v > 0. ? v : 0.;
+    case PSH_NL_SIGMOID: return 1. / (1. + exp(-v));
+    default: return v;
+    }
+}
+
+PSH_DEV double feat_apply(int id, double x) {
+    switch (id) {
+    case PSH_FEAT_SIGN: return (double)((x > 0.) - (x < 0.));
+    case PSH_FEAT_ABS: return fabs(x);
+    case PSH_FEAT_SQUARED: return x * x;
+    case PSH_FEAT_CUBED: return x * x * x;
+    case PSH_FEAT_SIG: return 1. / (1. + exp(-x));
+    case PSH_FEAT_BELL: return exp(-(x * x));
+    case PSH_FEAT_SIN: return sin(x);
+    case PSH_FEAT_COS: return cos(x);
+    case PSH_FEAT_SINSIN: { const double s = sin(x); return s * s; }
+    case PSH_FEAT_SINCOS: { double s, c; sincos(x, &s, &c); return s * c; }
+    default: return x;  // identity
+    }
+}
+
+// ------------------------------------------------------------------------------------------ one lane = one env
+template <int KIND> struct Lane {
+    using E = Env<KIND>;
+    E e;
+    double c_max, ret;
+    int curr_step, yielded, st, k;
+    bool done, live;  // live: this lane still has steps to execute
+
+    PSH_DEV void load(const RolloutArgs& a, long i) {
+        const long col = a.dp_index ? (long)a.dp_index[i] : i;
+        const DpCol p{a.domain_param, a.ld_dp, col};
+        e.setup(p);
+        c_max = task_c_max<KIND>(e, a.task);
+        double init[E::S];
+        for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * a.ld_init + i] : 0.;
+        e.reset(init, a.init_dim, (a.flags & PSH_F_SIMPLIFIED_DYN) != 0);
+        ret = 0.; curr_step = 0; yielded = 0; st = 0; k = 0; done = false;
+        live = a.max_steps > 0;
+    }
+
+    // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
+    PSH_DEV void pre_policy(const RolloutArgs& a, long i, double* obs) {
+        e.observe(obs);
+        bool nan = false;
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) nan = nan || (obs[r] != obs[r]);
+        if (a.obs) {
+#pragma unroll
+            for (int r = 0; r < E::O; ++r) a.obs[((long)k * E::O + r) * a.n_envs + i] = obs[r];
+        }
+        if (nan) { st |= PSH_ST_NAN; live = false; }
+    }
+
+    PSH_DEV void post_policy(const RolloutArgs& a, long i, double* act) {
+        bool nan = false;
+#pragma unroll
+        for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
+        if (nan) { st |= PSH_ST_NAN; live = false; return; }
+        const double rew = env_step<KIND>(e, a.task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false,
+                                          (a.flags & PSH_F_SIMPLIFIED_DYN) != 0, done, st);
+        if (a.act) {
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+        }
+        if (a.rew) a.rew[(long)k * a.n_envs + i] = rew;
+        ret += rew;
+        k += 1;
+        if (st & PSH_ST_NAN) live = false;
+        if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
+    }
+
+    PSH_DEV void store(const RolloutArgs& a, long i) {
+        if (a.obs) {  // final observation
+            double obs[E::O];
+            e.observe(obs);
+#pragma unroll
+            for (int r = 0; r < E::O; ++r) a.obs[((long)k * E::O + r) * a.n_envs + i] = obs[r];
+        }
+        a.ret[i] = ret;
+        a.length[i] = k;
+        a.status[i] = st;
+        if (a.final_state) {
+#pragma unroll
+            for (int r = 0; r < E::S; ++r) a.final_state[(long)r * a.n_envs + i] = e.s[r];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------- LinearPolicy rollouts
+// PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] of params.
+template <int KIND, bool PER_ENV>
+__global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
+    using E = Env<KIND>;
+    __shared__ double lds_w[PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = a.num_feat;
+    if (!PER_ENV) {
+        for (int j = threadIdx.x; j < E::A * F; j += blockDim.x) lds_w[j] = a.pol.params[j];
+        __syncthreads();
+    }
+    if (i >= a.n_envs) return;
+    const double* w = PER_ENV ? a.pol.params + (long)(a.pol.policy_index ? a.pol.policy_index[i] : 0) * a.pol.num_param : lds_w;
+    Lane<KIND> L;
+    L.load(a, i);
+    while (L.live) {
+        double obs[E::O], act[E::A];
+        L.pre_policy(a, i, obs);
+        if (!L.live) break;
+#pragma unroll
+        for (int r = 0; r < E::A; ++r) act[r] = 0.;
+        int n = 0;
+        for (int f = 0; f < a.pol.n_feats; ++f) {
+            const int id = a.pol.feats[f];
+            if (id == PSH_FEAT_CONST) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n];
+                n += 1;
+            } else {
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) {
+                    const double v = feat_apply(id, obs[q]);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * v;
+                }
+                n += E::O;
+            }
+        }
+        L.post_policy(a, i, act);
+    }
+    L.store(a, i);
+}
+
+// ---------------------------------------------------------------------------------------- FNNPolicy rollouts
+// Transposed formulation H^T[hidden, env] = W[hidden, k] . X^T[k, env] on v_mfma_f64_16x16x4_f64:
+//   A operand: lane l holds W[16t + (l & 15)][4s + (l >> 4)]           (weights, read from LDS)
+//   B operand: lane l holds X[k = 4s + (l >> 4)][env = l & 15]          (activations of 16 envs)
+//   D result : lane l, reg r holds H[16t + 4r + (l >> 4)][env = l & 15]
+// so reg r of output tile t IS the B operand of k-step 4t + r of the next layer: layers chain without any
+// cross-lane movement.  A wave owns 64 envs (lane = env for the dynamics) and runs the policy as 4 tiles of 16
+// envs; only the observations (through an LDS staging row per wave) and the action (two xor-shuffles) cross lanes.
+//
+// Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = OP/4 with OP = observation rows padded to 4:
+//   [HT*K0 frags of 64][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then [Wout: A*HP][bout: 2]
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int KIND, int HP>
+__global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
+    using E = Env<KIND>;
+    constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const w_lds = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    double* const stage = lds + a.lds_doubles + wave * (OP * 64);
+
+    for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    __syncthreads();
+
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < a.n_envs;
+    Lane<KIND> L;
+    if (valid) L.load(a, i); else L.live = false;
+
+    const int n_hidden = a.pol.n_hidden;
+    while (__any(L.live)) {
+        double obs[OP], act[E::A];
+#pragma unroll
+        for (int r = 0; r < OP; ++r) obs[r] = 0.;
+        if (L.live) L.pre_policy(a, i, obs);
+        // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
+#pragma unroll
+        for (int r = 0; r < OP; ++r) stage[r * 64 + lane] = obs[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (int tile = 0; tile < 4; ++tile) {
+            double x[KS], y[KS];
+            // layer 0
+            {
+                double xin[K0];
+#pragma unroll
+                for (int s = 0; s < K0; ++s) xin[s] = stage[(4 * s + q) * 64 + 16 * tile + c];
+                const double* wl = w_lds;
+                const double* bl = w_lds + HT * K0 * 64;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+#pragma unroll
+                    for (int s = 0; s < K0; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * K0 + s) * 64 + lane], xin[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
+                }
+                const int nl = a.pol.hidden_nonlin[0];
+#pragma unroll
+                for (int m = 0; m < KS; ++m) y[m] = nl_apply(nl, y[m]);
+            }
+            // further hidden layers
+            int off = HT * K0 * 64 + HP;
+            for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+                for (int m = 0; m < KS; ++m) x[m] = y[m];
+                const double* wl = w_lds + off;
+                const double* bl = wl + HT * KS * 64;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
+                }
+                const int nl = a.pol.hidden_nonlin[l];
+#pragma unroll
+                for (int m = 0; m < KS; ++m) y[m] = nl_apply(nl, y[m]);
+                off += HT * KS * 64 + HP;
+            }
+            // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
+            const double* wo = w_lds + off;
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) {
+                double p = 0.;
+#pragma unroll
+                for (int m = 0; m < KS; ++m) p += wo[r * HP + (m >> 2) * 16 + (m & 3) * 4 + q] * y[m];
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                p = nl_apply(a.pol.out_nonlin, p + wo[E::A * HP + r]);
+                if (q == tile) act[r] = p;
+            }
+        }
+        if (L.live) L.post_policy(a, i, act);
+    }
+    if (valid) L.store(a, i);
+}
+
+// Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
+__global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict__ out, int total, int O, int A, int HP,
+                           int OP, int n_hidden, int h0, int h1, int h2, int h3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int hs[4] = {h0, h1, h2, h3};
+    const int HT = HP / 16, KS = HP / 4, K0 = OP / 4;
+    int off = 0, poff = 0, last = O;
+    double v = 0.;
+    bool found = false;
+    for (int l = 0; l < n_hidden && !found; ++l) {
+        const int ks = (l == 0) ? K0 : KS, h = hs[l];
+        const int nfrag = HT * ks * 64;
+        if (idx < off + nfrag) {
+            const int f = (idx - off) >> 6, lane = (idx - off) & 63;
+            const int t = f / ks, s = f % ks;
+            const int row = 16 * t + (lane & 15), col = 4 * s + (lane >> 4);
+            v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
+            found = true;
+        } else if (idx < off + nfrag + HP) {
+            const int j = idx - off - nfrag;
+            v = (j < h) ? params[poff + h * last + j] : 0.;
+            found = true;
+        }
+        off += nfrag + HP;
+        poff += h * last + h;
+        last = h;
+    }
+    if (!found) {
+        const int j = idx - off;
+        if (j < A * HP) {
+            const int r = j / HP, m = j % HP;
+            v = (m < last) ? params[poff + r * last + m] : 0.;
+        } else {
+            const int r = j - A * HP;
+            v = (r < A) ? params[poff + A * last + r] : 0.;
+        }
+    }
+    out[idx] = v;
+}
+
+// --------------------------------------------------------------------------------------------- reset / step
+struct StepArgs {
+    int n_envs, max_steps, flags, init_dim;
+    double dt;
+    const double* domain_param; const int* dp_index; long ld_dp;
+    const double* init_state;
+    psh_task task;
+    double* state; int* curr_step; int* flags_io; double* act; double* obs; double* rew; int* done; int* status;
+};
+
+template <int KIND> __global__ __launch_bounds__(256) void k_reset(const StepArgs a) {
+    using E = Env<KIND>;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs) return;
+    const long N = a.n_envs;
+    E e;
+    e.setup(DpCol{a.domain_param, a.ld_dp, a.dp_index ? (long)a.dp_index[i] : i});
+    double init[E::S];
+    for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * N + i] : 0.;
+    e.reset(init, a.init_dim, (a.flags & PSH_F_SIMPLIFIED_DYN) != 0);
+#pragma unroll
+    for (int r = 0; r < E::S; ++r) a.state[r * N + i] = e.s[r];
+    if constexpr (KIND == PSH_ENV_QBB) {
+        a.state[8 * N + i] = e.plate[0];
+        a.state[9 * N + i] = e.plate[1];
+    }
+    a.curr_step[i] = 0;
+    a.flags_io[i] = 0;
+    double obs[E::O];
+    e.observe(obs);
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < E::O; ++r) { a.obs[r * N + i] = obs[r]; nan = nan || (obs[r] != obs[r]); }
+    if (a.status) a.status[i] = nan ? PSH_ST_NAN : 0;
+}
+
+template <int KIND> __global__ __launch_bounds__(256) void k_step(const StepArgs a) {
+    using E = Env<KIND>;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs) return;
+    const long N = a.n_envs;
+    E e;
+    e.setup(DpCol{a.domain_param, a.ld_dp, a.dp_index ? (long)a.dp_index[i] : i});
+    const double c_max = task_c_max<KIND>(e, a.task);
+#pragma unroll
+    for (int r = 0; r < E::S; ++r) e.s[r] = a.state[r * N + i];
+    if constexpr (KIND == PSH_ENV_QBB) {
+        e.plate[0] = a.state[8 * N + i];
+        e.plate[1] = a.state[9 * N + i];
+    }
+    e.refresh();
+    int curr_step = a.curr_step[i], yielded = a.flags_io[i] & 1, st = 0;
+    double act[E::A];
+#pragma unroll
+    for (int r = 0; r < E::A; ++r) { act[r] = a.act[r * N + i]; if (act[r] != act[r]) st |= PSH_ST_NAN; }
+    bool done = false;
+    const double rew = env_step<KIND>(e, a.task, c_max, curr_step, yielded, act, a.dt, a.max_steps,
+                                      (a.flags & PSH_F_MAX_STEPS_INF) != 0, (a.flags & PSH_F_SIMPLIFIED_DYN) != 0, done, st);
+#pragma unroll
+    for (int r = 0; r < E::A; ++r) a.act[r * N + i] = act[r];
+#pragma unroll
+    for (int r = 0; r < E::S; ++r) a.state[r * N + i] = e.s[r];
+    if constexpr (KIND == PSH_ENV_QBB) {
+        a.state[8 * N + i] = e.plate[0];
+        a.state[9 * N + i] = e.plate[1];
+    }
+    a.curr_step[i] = curr_step;
+    a.flags_io[i] = yielded;
+    double obs[E::O];
+    e.observe(obs);
+#pragma unroll
+    for (int r = 0; r < E::O; ++r) a.obs[r * N + i] = obs[r];
+    a.rew[i] = rew;
+    a.done[i] = done ? 1 : 0;
+    if (a.status) a.status[i] = st;
+}
+
+// ------------------------------------------------------------------------------- randomization / init sampling
+struct RandArgs {
+    int n_envs, n_rows, n_distr, ld_out;
+    uint64_t seed, env_offset;
+    psh_distr distr[PSH_MAX_DISTR];
+    double nominal[PSH_MAX_DP + 4];
+    double* out;
+};
+
+__global__ __launch_bounds__(256) void k_randomize(const RandArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs) return;
+    for (int r = 0; r < a.n_rows; ++r) a.out[(long)r * a.ld_out + i] = a.nominal[r];
+    for (int k = 0; k < a.n_distr; ++k) {
+        const psh_distr& d = a.distr[k];
+        double ua, ub, x = d.a;
+        psh_draw2(a.seed, a.env_offset + (uint64_t)i, (uint32_t)d.row, 0u, ua, ub);
+        if (d.kind == PSH_DISTR_NORMAL) {
+            const double r = sqrt(-2.0 * log(1.0 - ua));
+            x = d.a + d.b * (r * cos(2.0 * PSH_PI * ub));
+        } else if (d.kind == PSH_DISTR_UNIFORM) {
+            x = (d.a - d.b) + ua * ((d.a + d.b) - (d.a - d.b));
+        } else if (d.kind == PSH_DISTR_BERNOULLI) {
+            x = (ua < d.c) ? d.b : d.a;
+        }
+        if (d.kind != PSH_DISTR_CONST) {
+            x = fmin(fmax(x, d.clip_lo), d.clip_up);
+            if (d.roundint) x = rint(x);
+        }
+        a.out[(long)d.row * a.ld_out + i] = x;
+    }
+}
+
+struct InitArgs {
+    int env_kind, n_envs; long ld_dp, ld_out;
+    uint64_t seed, env_offset;
+    const double* domain_param; const int* dp_index; double* out;
+};
+
+__global__ __launch_bounds__(256) void k_sample_init(const InitArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs) return;
+    const long col = a.dp_index ? (long)a.dp_index[i] : i;
+    double lo[4], hi[4], u[5], ub;
+    const uint64_t env = a.env_offset + (uint64_t)i;
+    for (int r = 0; r < 5; ++r) psh_draw2(a.seed, env, (uint32_t)r, 1u, u[r], ub);
+    int I = 4;
+    switch (a.env_kind) {
+    case PSH_ENV_QQ: {
+        const double m[4] = {2. / 180 * PSH_PI, 1. / 180 * PSH_PI, 0.5 / 180 * PSH_PI, 0.5 / 180 * PSH_PI};
+        for (int r = 0; r < 4; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
+        break;
+    }
+    case PSH_ENV_QCP_SU: {
+        const double m[4] = {0.03, 1 / 180. * PSH_PI, 0.005, 2 / 180. * PSH_PI};
+        for (int r = 0; r < 4; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
+        break;
+    }
+    case PSH_ENV_QCP_ST: {
+        const double off = 8 / 180. * PSH_PI;
+        lo[0] = -0.05; hi[0] = 0.05; lo[1] = PSH_PI - off; hi[1] = PSH_PI + off;
+        lo[2] = -0.05; hi[2] = 0.05; lo[3] = -8 / 180. * PSH_PI; hi[3] = 8 / 180. * PSH_PI;
+        break;
+    }
+    case PSH_ENV_QBB: {
+        const double l_plate = a.domain_param[3 * a.ld_dp + col];
+        lo[0] = 0.75 * l_plate / 2; hi[0] = 0.8 * l_plate / 2; lo[1] = -PSH_PI; hi[1] = PSH_PI;
+        lo[2] = -0.05 * 0.5; hi[2] = 0.05 * 0.5; lo[3] = -0.05 * 0.5; hi[3] = 0.05 * 0.5;
+        break;
+    }
+    case PSH_ENV_BOB: {
+        const double l_beam = a.domain_param[4 * a.ld_dp + col];
+        const bool right = u[4] >= 0.5;
+        lo[0] = right ? 0.7 * l_beam / 2. : -0.8 * l_beam / 2.;
+        hi[0] = right ? 0.8 * l_beam / 2. : -0.7 * l_beam / 2.;
+        lo[1] = -5 / 180. * PSH_PI; hi[1] = 5 / 180. * PSH_PI;
+        lo[2] = -0.02 * 10.; hi[2] = 0.02 * 10.; lo[3] = -0.02 * PSH_PI; hi[3] = 0.02 * PSH_PI;
+        break;
+    }
+    default:  // OMO
+        I = 2;
+        lo[0] = -0.75 * 1.; hi[0] = -0.65 * 1.; lo[1] = -0.01 * 10.; hi[1] = 0.01 * 10.;
+        lo[2] = hi[2] = lo[3] = hi[3] = 0.;
+    }
+    double v[4];
+    for (int r = 0; r < 4; ++r) v[r] = lo[r] + u[r] * (hi[r] - lo[r]);
+    if (a.env_kind == PSH_ENV_QBB) {
+        const double rad = v[0], phi = v[1];
+        double sn, cs;
+        sincos(phi, &sn, &cs);
+        v[0] = rad * cs; v[1] = rad * sn;
+    }
+    for (int r = 0; r < I; ++r) a.out[(long)r * a.ld_out + i] = v[r];
+}
+
+__global__ __launch_bounds__(256) void k_qbb_ik(int n, const double* th, const double* r_arm, const double* l_plate, double* ang) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ang[i] = qbb_ik(th[i], r_arm[i], l_plate[i]);
+}
+
+// one wave per group: mean of group_size consecutive returns
+__global__ __launch_bounds__(256) void k_segment_mean(int n_groups, int group_size, const double* ret, double* mean) {
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= n_groups) return;
+    double acc = 0.;
+    for (int j = lane; j < group_size; j += 64) acc += ret[(long)g * group_size + j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) mean[g] = acc / group_size;
+}
+
+// =================================================================================================== C ABI
+static bool dims_of(int kind, int32_t d[5]) {
+    switch (kind) {
+    case PSH_ENV_QQ: d[0] = 4; d[1] = 6; d[2] = 1; d[3] = 10; d[4] = 4; return true;
+    case PSH_ENV_QCP_SU:
+    case PSH_ENV_QCP_ST: d[0] = 4; d[1] = 5; d[2] = 1; d[3] = 14; d[4] = 4; return true;
+    case PSH_ENV_QBB: d[0] = 8; d[1] = 8; d[2] = 2; d[3] = 20; d[4] = 4; return true;
+    case PSH_ENV_BOB: d[0] = 4; d[1] = 4; d[2] = 1; d[3] = 8; d[4] = 4; return true;
+    case PSH_ENV_OMO: d[0] = 2; d[1] = 2; d[2] = 1; d[3] = 3; d[4] = 2; return true;
+    }
+    return false;
+}
+
+extern "C" int psh_version(void) { return PSH_VERSION; }
+
+extern "C" int psh_env_dims(int env_kind, int32_t dims[5]) { return dims_of(env_kind, dims) ? PSH_OK : PSH_ERR_ARG; }
+
+extern "C" int psh_create(int hip_device, psh_ctx** out) {
+    if (!out) return PSH_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || hip_device < 0 || hip_device >= n) return PSH_ERR_NODEV;
+    if (hipSetDevice(hip_device) != hipSuccess) return PSH_ERR_NODEV;
+    psh_ctx* c = new (std::nothrow) psh_ctx();
+    if (!c) return PSH_ERR_ARG;
+    memset(c, 0, sizeof *c);
+    c->device = hip_device;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return PSH_ERR_HIP;
+    }
+    *out = c;
+    return PSH_OK;
+}
+
+extern "C" void psh_destroy(psh_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->wfrag) (void)hipFree(c->wfrag);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" const char* psh_last_error(const psh_ctx* c) { return c ? c->err : "no context"; }
+
+static int check_task(psh_ctx* c, const psh_task& t, int S) {
+    if (t.rew_kind < 0 || t.rew_kind > PSH_REW_SWINGUP) { set_err(c, "unknown reward kind"); return PSH_ERR_ARG; }
+    if (t.rew_kind == PSH_REW_SWINGUP && (t.idx_x < 0 || t.idx_x >= S || t.idx_th < 0 || t.idx_th >= S)) {
+        set_err(c, "swing-up reward indices outside the state");
+        return PSH_ERR_ARG;
+    }
+    const int m = t.final_mode;
+    if (m & PSH_FIN_ENABLED) {
+        const bool ap = m & PSH_FIN_ALWAYS_POSITIVE, an = m & PSH_FIN_ALWAYS_NEGATIVE;
+        const bool sd = m & PSH_FIN_STATE_DEPENDENT, td = m & PSH_FIN_TIME_DEPENDENT;
+        // the combinations FinalRewTask.compute_final_rew implements (final_reward.py:87-183)
+        const bool ok = (!ap && !an) || (ap && !an && !(sd && td)) || (!ap && an && !(sd && td));
+        if (!ok) { set_err(c, "FinalRewMode combination not implemented by the reference"); return PSH_ERR_UNSUPPORTED; }
+    }
+    return PSH_OK;
+}
+
+template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, RolloutArgs& a, hipStream_t st) {
+    using E = Env<KIND>;
+    const psh_policy& p = d->policy;
+    const bool per_env = p.policy_index != nullptr && p.n_policies > 1;
+    if (p.kind == PSH_POL_LINEAR) {
+        if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }
+        int F = 0;
+        for (int f = 0; f < p.n_feats; ++f) {
+            if (p.feats[f] < 0 || p.feats[f] > PSH_FEAT_SINCOS) { set_err(c, "unknown feature id"); return PSH_ERR_ARG; }
+            F += (p.feats[f] == PSH_FEAT_CONST) ? 1 : E::O;
+        }
+        if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
+        a.num_feat = F;
+        const dim3 block(256), grid((unsigned)((d->n_envs + 255) / 256));
+        if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
+        if (per_env) hipLaunchKernelGGL((k_rollout_linear<KIND, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_rollout_linear<KIND, false>), grid, block, 0, st, a);
+        PSH_HIP(c, hipGetLastError());
+        if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
+        return PSH_OK;
+    }
+    if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
+    if (p.n_hidden < 1 || p.n_hidden > PSH_MAX_HIDDEN) { set_err(c, "FNNPolicy needs 1..4 hidden layers"); return PSH_ERR_ARG; }
+    int hmax = 0, np = 0, last = E::O;
+    for (int l = 0; l < p.n_hidden; ++l) {
+        const int h = p.hidden[l];
+        if (h < 1 || h > PSH_MAX_WIDTH) { set_err(c, "hidden sizes must be within 1..64"); return PSH_ERR_ARG; }
+        if (p.hidden_nonlin[l] < 0 || p.hidden_nonlin[l] > PSH_NL_SIGMOID) { set_err(c, "unknown nonlinearity"); return PSH_ERR_ARG; }
+        hmax = h > hmax ? h : hmax;
+        np += h * last + h;
+        last = h;
+    }
+    np += E::A * last + E::A;
+    if (p.num_param != np) { set_err(c, "num_param does not match the FNNPolicy layout"); return PSH_ERR_ARG; }
+    if (per_env) { set_err(c, "per-env FNN policies are not supported yet"); return PSH_ERR_UNSUPPORTED; }
+    const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
+    const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = OP / 4;
+    const int total = HT * K0 * 64 + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
+    if ((size_t)total > c->wfrag_doubles) {
+        if (c->wfrag) PSH_HIP(c, hipFree(c->wfrag));
+        c->wfrag = nullptr; c->wfrag_doubles = 0;
+        PSH_HIP(c, hipMalloc(&c->wfrag, (size_t)total * sizeof(double)));
+        c->wfrag_doubles = (size_t)total;
+    }
+    hipLaunchKernelGGL(k_pack_fnn, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, (int)E::O, (int)E::A,
+                       HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
+    PSH_HIP(c, hipGetLastError());
+    a.wfrag = c->wfrag;
+    a.lds_doubles = total;
+    constexpr int BLOCK = 512;
+    const size_t lds_bytes = ((size_t)total + (BLOCK / 64) * OP * 64) * sizeof(double);
+    const dim3 block(BLOCK), grid((unsigned)((d->n_envs + BLOCK - 1) / BLOCK));
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
+    if (HP == 16) {
+        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((k_rollout_fnn<KIND, 16>), grid, block, lds_bytes, st, a);
+    } else if (HP == 32) {
+        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((k_rollout_fnn<KIND, 32>), grid, block, lds_bytes, st, a);
+    } else {
+        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((k_rollout_fnn<KIND, 64>), grid, block, lds_bytes, st, a);
+    }
+    PSH_HIP(c, hipGetLastError());
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
+    return PSH_OK;
+}
+
+extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
+    if (!c || !d) return PSH_ERR_ARG;
+    int32_t dm[5];
+    if (!dims_of(d->env_kind, dm)) { set_err(c, "unknown env_kind"); return PSH_ERR_ARG; }
+    if (d->n_envs < 0 || d->max_steps < 1 || !(d->dt > 0.)) { set_err(c, "n_envs >= 0, max_steps >= 1 and dt > 0 are required"); return PSH_ERR_ARG; }
+    if (d->n_envs == 0) return PSH_OK;
+    if (!d->init_state || !d->domain_param || !d->ret || !d->length || !d->status || !d->policy.params) {
+        set_err(c, "init_state, domain_param, policy.params, ret, length and status must be non-NULL");
+        return PSH_ERR_ARG;
+    }
+    const bool full_state = d->init_dim == dm[0];
+    if (!(d->init_dim == dm[4] || full_state)) { set_err(c, "init_dim must be the init-space or the state dimension"); return PSH_ERR_ARG; }
+    if (d->ld_init < d->n_envs || d->ld_dp < 1 || (!d->dp_index && d->ld_dp < d->n_envs)) { set_err(c, "leading dimensions too small"); return PSH_ERR_ARG; }
+    if (d->act_delay_row >= 0) { set_err(c, "fused action delay is not supported yet"); return PSH_ERR_UNSUPPORTED; }
+    if (d->policy.n_policies < 1) { set_err(c, "n_policies must be >= 1"); return PSH_ERR_ARG; }
+    int rc = check_task(c, d->task, dm[0]);
+    if (rc != PSH_OK) return rc;
+    PSH_HIP(c, hipSetDevice(c->device));
+    RolloutArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
+    a.init_state = d->init_state; a.ld_init = d->ld_init;
+    a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
+    a.task = d->task; a.pol = d->policy;
+    a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
+    a.obs = d->obs; a.act = d->act; a.rew = d->rew;
+    hipStream_t st = (hipStream_t)d->stream;
+    c->timed = 1;
+    switch (d->env_kind) {
+    case PSH_ENV_QQ: return launch_rollout<PSH_ENV_QQ>(c, d, a, st);
+    case PSH_ENV_QCP_SU: return launch_rollout<PSH_ENV_QCP_SU>(c, d, a, st);
+    case PSH_ENV_QCP_ST: return launch_rollout<PSH_ENV_QCP_ST>(c, d, a, st);
+    case PSH_ENV_QBB: return launch_rollout<PSH_ENV_QBB>(c, d, a, st);
+    case PSH_ENV_BOB: return launch_rollout<PSH_ENV_BOB>(c, d, a, st);
+    default: return launch_rollout<PSH_ENV_OMO>(c, d, a, st);
+    }
+}
+
+extern "C" float psh_last_rollout_ms(psh_ctx* c) {
+    if (!c || !c->timed) return -1.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+static int fill_step_args(psh_ctx* c, const psh_step_desc* d, StepArgs& a, int32_t dm[5], bool is_reset) {
+    if (!c || !d) return PSH_ERR_ARG;
+    if (!dims_of(d->env_kind, dm)) { set_err(c, "unknown env_kind"); return PSH_ERR_ARG; }
+    if (d->n_envs < 0) { set_err(c, "n_envs must be >= 0"); return PSH_ERR_ARG; }
+    if (!d->domain_param || !d->state || !d->curr_step || !d->flags_io || !d->obs) { set_err(c, "domain_param, state, curr_step, flags_io and obs must be non-NULL"); return PSH_ERR_ARG; }
+    if (is_reset) {
+        if (!d->init_state || !(d->init_dim == dm[4] || d->init_dim == dm[0])) { set_err(c, "psh_reset needs init_state with the init-space or the state dimension"); return PSH_ERR_ARG; }
+    } else {
+        if (!d->act || !d->rew || !d->done || !(d->dt > 0.) || d->max_steps < 1) { set_err(c, "psh_step needs act, rew, done, dt > 0 and max_steps >= 1"); return PSH_ERR_ARG; }
+    }
+    if (d->ld_dp < 1 || (!d->dp_index && d->ld_dp < d->n_envs)) { set_err(c, "ld_dp too small"); return PSH_ERR_ARG; }
+    int rc = check_task(c, d->task, dm[0]);
+    if (rc != PSH_OK) return rc;
+    memset(&a, 0, sizeof a);
+    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
+    a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp; a.init_state = d->init_state;
+    a.task = d->task;
+    a.state = d->state; a.curr_step = d->curr_step; a.flags_io = d->flags_io; a.act = d->act; a.obs = d->obs;
+    a.rew = d->rew; a.done = d->done; a.status = d->status;
+    return PSH_OK;
+}
+
+#define PSH_DISPATCH_KIND(kind, KERNEL, grid, block, st, args)                                         \
+    switch (kind) {                                                                                    \
+    case PSH_ENV_QQ: hipLaunchKernelGGL((KERNEL<PSH_ENV_QQ>), grid, block, 0, st, args); break;       \
+    case PSH_ENV_QCP_SU: hipLaunchKernelGGL((KERNEL<PSH_ENV_QCP_SU>), grid, block, 0, st, args); break; \
+    case PSH_ENV_QCP_ST: hipLaunchKernelGGL((KERNEL<PSH_ENV_QCP_ST>), grid, block, 0, st, args); break; \
+    case PSH_ENV_QBB: hipLaunchKernelGGL((KERNEL<PSH_ENV_QBB>), grid, block, 0, st, args); break;     \
+    case PSH_ENV_BOB: hipLaunchKernelGGL((KERNEL<PSH_ENV_BOB>), grid, block, 0, st, args); break;     \
+    default: hipLaunchKernelGGL((KERNEL<PSH_ENV_OMO>), grid, block, 0, st, args); break;              \
+    }
+
+extern "C" int psh_reset(psh_ctx* c, const psh_step_desc* d) {
+    StepArgs a;
+    int32_t dm[5];
+    int rc = fill_step_args(c, d, a, dm, true);
+    if (rc != PSH_OK || d->n_envs == 0) return rc;
+    PSH_HIP(c, hipSetDevice(c->device));
+    const dim3 block(256), grid((unsigned)((d->n_envs + 255) / 256));
+    hipStream_t st = (hipStream_t)d->stream;
+    PSH_DISPATCH_KIND(d->env_kind, k_reset, grid, block, st, a);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_step(psh_ctx* c, const psh_step_desc* d) {
+    StepArgs a;
+    int32_t dm[5];
+    int rc = fill_step_args(c, d, a, dm, false);
+    if (rc != PSH_OK || d->n_envs == 0) return rc;
+    PSH_HIP(c, hipSetDevice(c->device));
+    const dim3 block(256), grid((unsigned)((d->n_envs + 255) / 256));
+    hipStream_t st = (hipStream_t)d->stream;
+    PSH_DISPATCH_KIND(d->env_kind, k_step, grid, block, st, a);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_randomize(psh_ctx* c, const psh_rand_desc* d) {
+    if (!c || !d) return PSH_ERR_ARG;
+    if (d->n_envs < 0 || d->n_rows < 1 || d->n_rows > PSH_MAX_DP + 4 || d->n_distr < 0 || d->n_distr > PSH_MAX_DISTR || !d->out || d->ld_out < d->n_envs) {
+        set_err(c, "invalid randomization descriptor");
+        return PSH_ERR_ARG;
+    }
+    for (int k = 0; k < d->n_distr; ++k) {
+        const psh_distr& q = d->distr[k];
+        if (q.row < 0 || q.row >= d->n_rows || q.kind < 0 || q.kind > PSH_DISTR_BERNOULLI) { set_err(c, "invalid distribution entry"); return PSH_ERR_ARG; }
+    }
+    if (d->n_envs == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    RandArgs a;
+    a.n_envs = d->n_envs; a.n_rows = d->n_rows; a.n_distr = d->n_distr; a.ld_out = d->ld_out;
+    a.seed = d->seed; a.env_offset = d->env_offset;
+    memcpy(a.distr, d->distr, sizeof a.distr);
+    memcpy(a.nominal, d->nominal, sizeof a.nominal);
+    a.out = d->out;
+    hipLaunchKernelGGL(k_randomize, dim3((d->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)d->stream, a);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_sample_init(psh_ctx* c, const psh_init_desc* d) {
+    if (!c || !d) return PSH_ERR_ARG;
+    int32_t dm[5];
+    if (!dims_of(d->env_kind, dm)) { set_err(c, "unknown env_kind"); return PSH_ERR_ARG; }
+    if (d->n_envs < 0 || !d->out || d->ld_out < d->n_envs) { set_err(c, "invalid init-sampling descriptor"); return PSH_ERR_ARG; }
+    const bool needs_dp = d->env_kind == PSH_ENV_QBB || d->env_kind == PSH_ENV_BOB;
+    if (needs_dp && (!d->domain_param || d->ld_dp < 1 || (!d->dp_index && d->ld_dp < d->n_envs))) { set_err(c, "this init space depends on the domain parameters"); return PSH_ERR_ARG; }
+    if (d->n_envs == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    InitArgs a;
+    a.env_kind = d->env_kind; a.n_envs = d->n_envs; a.ld_dp = d->ld_dp; a.ld_out = d->ld_out;
+    a.seed = d->seed; a.env_offset = d->env_offset;
+    a.domain_param = d->domain_param; a.dp_index = needs_dp ? d->dp_index : nullptr; a.out = d->out;
+    hipLaunchKernelGGL(k_sample_init, dim3((d->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)d->stream, a);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_qbb_ik(psh_ctx* c, int32_t n, const double* th, const double* r_arm, const double* l_plate, double* ang, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!th || !r_arm || !l_plate || !ang))) { set_err(c, "invalid IK arguments"); return PSH_ERR_ARG; }
+    if (n == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_qbb_ik, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, th, r_arm, l_plate, ang);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_segment_mean(psh_ctx* c, int32_t n_groups, int32_t group_size, const double* ret, double* mean, void* stream) {
+    if (!c || n_groups < 0 || group_size < 1 || (n_groups > 0 && (!ret || !mean))) { set_err(c, "invalid segment-mean arguments"); return PSH_ERR_ARG; }
+    if (n_groups == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_segment_mean, dim3((n_groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_groups, group_size, ret, mean);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
