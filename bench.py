@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: domain-randomized env-steps/sec (QQube, FNN policy) on N MI355X.
+
+Workload (per GPU, weak scaling): the QQube sweep of BASELINE.json configs[4] — `--sets` domain-parameter sets
+(randomizer distributions whose Mp/Mr/Lp/Lr means and stds are perturbed within +-30 % of the default randomizer)
+x `--rollouts` rollouts each, QQubeSim dt = 1/500, T = 600, FNNPolicy 6-64-64-1 tanh with the reference's
+initialisation (orthogonal weights, N(0,1) biases, seed 0).  One "step" = one pass of the hot path over that batch:
+on-device domain randomization + init-state sampling + the fused rollout kernel + per-set return statistics
+(+ one all-gather of those statistics across ranks).  Only env-steps executed before each env's `done` are counted.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from simurlacra_amd import _abi as abi, envdefs  # noqa: E402
+from simurlacra_amd.engine import get_engine  # noqa: E402
+from simurlacra_amd.specs import PolicySpec  # noqa: E402
+
+FLOP_PER_STEP = 9352          # algorithmic fp64 flop per env-step, QQube + FNN 64x64 (transcendentals counted as 1)
+FP64_PEAK_TFLOPS = 78.6       # MI355X dense FP64 (matrix = vector rate: half the 157.3 TF FP32 peak)
+DT, T = 1/500., 600
+
+
+def reference_fnn_params(sizes, seed):
+    """ FNNPolicy parameters initialised as Pyrado/pyrado/policies/initialization.py:26-40 does (orthogonal weights,
+    standard-normal biases), flattened in parameters() order. """
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    for fan_in, fan_out in zip(sizes[:-1], sizes[1:]):
+        a = torch.randn((fan_out, fan_in), dtype=torch.float64, generator=g)
+        # torch.nn.init.orthogonal_: QR of the (tall) Gaussian matrix with the sign fix on the diagonal of R
+        tall = a if fan_out >= fan_in else a.t()
+        q, r = torch.linalg.qr(tall)
+        q = q*torch.sign(torch.diagonal(r)).unsqueeze(0)
+        w = q if fan_out >= fan_in else q.t()
+        parts += [w.reshape(-1), torch.randn(fan_out, dtype=torch.float64, generator=g)]
+    return torch.cat(parts)
+
+
+def qq_set_distrs(set_id):
+    """ Randomizer of domain-parameter set `set_id`: the default QQube randomizer
+    (Pyrado/pyrado/domain_randomization/default_randomizers.py:253-263) with the means and stds of Mp, Mr, Lp, Lr
+    (the BayRn map, :413-429) scaled by factors in [0.7, 1.3] drawn from a generator seeded with the set id. """
+    nom = envdefs.nominal_domain_param(abi.ENV_QQ)
+    names = list(nom.keys())
+    clip = dict(g=1e-3, Rm=1e-3, km=1e-4, Mr=1e-4, Lr=1e-4, Dr=1e-9, Mp=1e-4, Lp=1e-4, Dp=1e-9)
+    rng = np.random.default_rng(1000 + set_id)
+    distrs = []
+    for name, lo in clip.items():
+        mean, std = nom[name], nom[name]/5
+        if name in ('Mp', 'Mr', 'Lp', 'Lr'):
+            mean *= rng.uniform(0.7, 1.3)
+            std *= rng.uniform(0.7, 1.3)
+        distrs.append(dict(kind=abi.DISTR_NORMAL, row=names.index(name), a=mean, b=std, clip_lo=lo))
+    return distrs, list(nom.values())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--sets', type=int, default=8, help='domain-parameter sets per GPU')
+    ap.add_argument('--rollouts', type=int, default=262144, help='rollouts per domain-parameter set')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist = None
+    torch.cuda.set_device(local_rank)
+    eng = get_engine(local_rank)
+    dev = eng.device
+
+    S, O, A, P, _ = abi.ENV_DIMS[abi.ENV_QQ]
+    task_c = envdefs.default_task_spec(abi.ENV_QQ).to_c(S, A)
+    ps = PolicySpec('fnn', O, A, hidden=[64, 64], hidden_nonlin=['tanh', 'tanh'])
+    params = reference_fnn_params([O, 64, 64, A], seed=0).to(dev)
+    n_sets, R = args.sets, args.rollouts
+    N = n_sets*R
+    sets = [qq_set_distrs(rank*n_sets + j) for j in range(n_sets)]
+    dp = torch.empty((P, N), dtype=torch.float64, device=dev)
+    out = None
+
+    def one_step(it):
+        nonlocal out
+        for j, (distrs, nominal) in enumerate(sets):
+            g0 = (rank*n_sets + j)*R                       # global index of the set's first env
+            dp[:, j*R:(j + 1)*R] = eng.randomize(R, distrs, nominal, seed=it, env_offset=g0)
+        init = eng.sample_init(abi.ENV_QQ, N, dp, seed=it, env_offset=rank*N)
+        out = eng.rollout(abi.ENV_QQ, DT, T, task_c, ps, params, init, dp, final_state=False, out=out)
+        ret = out['ret'].view(n_sets, R)
+        stats = torch.stack([ret.mean(dim=1), ret.var(dim=1), torch.full((n_sets,), float(R), device=dev,
+                                                                         dtype=torch.float64)], dim=1)
+        steps = out['length'].sum(dtype=torch.int64)
+        if dist is not None:
+            gathered = torch.empty((world*n_sets, 3), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(gathered, stats)
+            stats = gathered
+        return steps, stats
+
+    for w in range(args.warmup):
+        one_step(-1 - w)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total_steps = torch.zeros((), dtype=torch.int64, device=dev)
+    for it in range(args.steps):
+        steps, stats = one_step(it)
+        total_steps += steps
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # whole-job numbers: max time over ranks, sum of executed env-steps over ranks
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total = int(total_steps.item())
+
+    # dominant kernel: one more pass, its duration taken from HIP events recorded on the launch stream
+    steps_k, _ = one_step(args.steps)
+    k_ms = eng.last_rollout_ms()
+    steps_k = int(steps_k.item())
+    achieved = FLOP_PER_STEP*steps_k/(k_ms*1e-3)/1e12
+
+    res = None
+    if rank == 0:
+        res = {
+            'metric': 'domain-randomized env-steps/sec (QQube, FNN policy)',
+            'value': total/elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3*elapsed/args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'QQubeSim dt=1/500 T=600, DomainRandomizer (default QQ randomizer, per-set Mp/Mr/Lp/Lr '
+                                   'mean/std +-30%), FNNPolicy 6-64-64-1 tanh (orthogonal init seed 0)',
+                       'domain_param_sets_per_gpu': n_sets, 'rollouts_per_set': R, 'envs_per_gpu': N,
+                       'env_steps_counted': 'executed before done', 'parallelism': f'env-sharded x{world}'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'k_rollout_fnn<QQ,64>', 'kernel_ms': k_ms, 'env_steps_per_launch': steps_k,
+                         'flop_per_env_step': FLOP_PER_STEP},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(eng, sets, task_c, ps, params)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(eng, sets, task_c, ps, params, target_s=12.0):
+    """ The C oracle (scalar fp64 restatement of the reference, OpenMP over envs) on a bounded sample of the same
+    workload, timed on this box's host cores. """
+    from oracle import oracle_lib as orc
+    threads = min(orc.lib().orc_num_threads(), 16)
+    distrs, nominal = sets[0]
+
+    def sample(n, seed):
+        dp = eng.randomize(n, distrs, nominal, seed=seed, env_offset=0)
+        init = eng.sample_init(abi.ENV_QQ, n, dp, seed=seed, env_offset=0)
+        return dp.cpu().numpy(), init.cpu().numpy()
+
+    p = params.cpu().numpy()
+    dp, init = sample(4096, 12345)
+    t0 = time.perf_counter()
+    o = orc.rollout(abi.ENV_QQ, DT, T, task_c, ps, p, init, dp, n_threads=threads)
+    probe = time.perf_counter() - t0
+    rate = o['length'].sum()/probe
+    n = int(min(max(4096, target_s*rate/max(1., o['length'].mean())), 4_000_000))
+    dp, init = sample(n, 54321)
+    t0 = time.perf_counter()
+    o = orc.rollout(abi.ENV_QQ, DT, T, task_c, ps, p, init, dp, n_threads=threads)
+    el = time.perf_counter() - t0
+    return {'value': float(o['length'].sum()/el), 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} envs of the same workload (set 0), {int(o["length"].sum())} env-steps in {el:.1f} s, '
+                      f'C restatement of the reference (oracle/pysim_oracle.c, -O2, OpenMP over envs)'}
+
+
+if __name__ == '__main__':
+    main()

@@ -292,12 +292,13 @@ class NpEnv:
                 x_ = trq - p['Dr']*thd - c0
                 y_ = -p['Dp']*ald - c1
                 return thd, ald, float((c*x_ - b*y_)/det), float((a*y_ - b*x_)/det)
-            thd, ald, thdd, aldd = dyn(self.state, act)
+            u = float(act[0])
+            thd, ald, thdd, aldd = dyn(self.state, u)
             kk = np.zeros((4, 4))
             kk[0, :] = np.array([thd, ald, thdd, aldd])
             for j in range(1, 4):
                 s = self.state + (dt/2. if j <= 2 else dt)*kk[j - 1, :]
-                thd, ald, thdd, aldd = dyn(self.state, act)  # un-advanced state, as the reference does
+                thd, ald, thdd, aldd = dyn(self.state, u)  # un-advanced state, as the reference does
                 kk[j, :] = np.array([s[2], s[3], thdd, aldd])
             self.state += dt/6*(kk[0] + 2*kk[1] + 2*kk[2] + kk[3])
         elif k in ('qcp-su', 'qcp-st'):  # pysim/quanser_cartpole.py:95-124

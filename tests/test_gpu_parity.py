@@ -75,3 +75,116 @@ def test_reset_step(eng, orc, kind):
         assert cases.rel_err(r.cpu().numpy(), r_ref) <= TOL
         assert cases.rel_err(act_t.cpu().numpy(), a_ref) <= TOL
         np.testing.assert_array_equal(mem['curr_step'].cpu().numpy(), mem_ref['curr_step'])
+
+
+import glob
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'rollout_*.npz'))), ids=os.path.basename)
+def test_golden_vectors(eng, path):
+    """ The committed golden vectors (NumPy restatement of the reference, tests/golden/make_golden.py). """
+    from simurlacra_amd import envdefs
+    from simurlacra_amd.specs import PolicySpec
+    g = np.load(path)
+    kind, T = int(g['kind']), int(g['T'])
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    if len(g['hidden']) == 0:
+        ps = PolicySpec('linear', O, A, feats=[str(f) for f in g['feats']])
+    else:
+        ps = PolicySpec('fnn', O, A, hidden=[int(h) for h in g['hidden']], hidden_nonlin=['tanh']*len(g['hidden']))
+    out = eng.rollout(kind, float(g['dt']), T, task_c, ps, g['params'], g['init'], g['dp'], record=True)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), g['length'])
+    for k in ('obs', 'act', 'rew', 'ret'):
+        assert cases.rel_err(out[k].cpu().numpy(), g[k]) <= TOL, k
+
+
+def test_randomize_matches_oracle(eng, orc):
+    """ Same Philox counters on both sides: integer stream bit-exact, so Uniform/Bernoulli/rounded values are
+    identical and Normal values differ only by the last bits of log/sqrt/cos. """
+    nominal = [1., 2., 3., 4., 5.]
+    distrs = [dict(kind=abi.DISTR_NORMAL, row=0, a=5., b=2., clip_lo=1.5),
+              dict(kind=abi.DISTR_UNIFORM, row=1, a=3., b=1.),
+              dict(kind=abi.DISTR_BERNOULLI, row=2, a=-1., b=7., c=0.7),
+              dict(kind=abi.DISTR_UNIFORM, row=3, a=5., b=5., clip_lo=0, roundint=1)]
+    n = 100000
+    ref = orc.randomize(n, distrs, nominal, seed=42, env_offset=123456789012)
+    got = eng.randomize(n, distrs, nominal, seed=42, env_offset=123456789012).cpu().numpy()
+    np.testing.assert_array_equal(got[1:], ref[1:])
+    assert cases.rel_err(got[0], ref[0]) <= 1e-13
+
+
+@pytest.mark.parametrize('kind', cases.KINDS)
+def test_sample_init_matches_oracle(eng, orc, kind):
+    rng = np.random.default_rng(kind)
+    dp = cases.domain_params(kind, 5000, rng)
+    ref = orc.sample_init(kind, 5000, dp, seed=7, env_offset=99)
+    got = eng.sample_init(kind, 5000, dp, seed=7, env_offset=99).cpu().numpy()
+    assert cases.rel_err(got, ref) <= 1e-14
+
+
+def test_qbb_ik_matches_oracle(eng, orc):
+    th = np.linspace(-np.pi/2.1, np.pi/2.1, 50)
+    r_arm = np.full(50, 0.0254)*np.linspace(0.8, 1.2, 50)
+    l_plate = np.full(50, 0.275)*np.linspace(1.2, 0.8, 50)
+    got = eng.qbb_ik(th, r_arm, l_plate).cpu().numpy()
+    ref = np.array([orc.qbb_ik(a, b, c) for a, b, c in zip(th, r_arm, l_plate)])
+    assert np.all(np.isfinite(got)) and cases.rel_err(got, ref) <= 1e-12
+
+
+def test_segment_mean(eng):
+    import torch
+    ret = torch.randn(37*10, dtype=torch.float64, device=eng.device)
+    got = eng.segment_mean(ret, 10).cpu().numpy()
+    np.testing.assert_allclose(got, ret.view(37, 10).mean(dim=1).cpu().numpy(), rtol=1e-14)
+
+
+def test_buffer_mode_and_population_mode(eng, orc):
+    """ dp_index (DomainRandWrapperBuffer / sweep mode) and policy_index (one LinearPolicy row per env) """
+    kind = abi.ENV_BOB
+    case = cases.make_case(kind, 256, seed=5, policy='linear')
+    rng = np.random.default_rng(1)
+    table = case['dp'][:, :16].copy()
+    dp_index = rng.integers(0, 16, 256).astype(np.int32)
+    pop = 0.5*rng.standard_normal((8, case['ps'].num_param))
+    policy_index = (np.arange(256)//32).astype(np.int32)
+    kw = dict(dp_index=dp_index, policy_index=policy_index, record=True)
+    ref = orc.rollout(kind, case['dt'], 50, case['task_c'], case['ps'], pop, case['init'], table, **kw)
+    out = eng.rollout(kind, case['dt'], 50, case['task_c'], case['ps'], pop, case['init'], table, **kw)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    for k in ('obs', 'act', 'rew', 'ret'):
+        assert cases.rel_err(out[k].cpu().numpy(), ref[k]) <= TOL, k
+
+
+def test_ragged_and_empty_batches(eng, orc):
+    """ N not a multiple of the wave/block size, N = 1 and N = 0 """
+    kind = abi.ENV_QQ
+    for n in (1, 63, 65, 513):
+        case = cases.make_case(kind, n, seed=n, policy='fnn', hidden=(64, 64))
+        _compare_rollouts(eng, orc, case, T=30)
+    case = cases.make_case(kind, 4, seed=1, policy='linear')
+    out = eng.rollout(kind, case['dt'], 10, case['task_c'], case['ps'], case['params'], case['init'][:, :0], case['dp'][:, :1])
+    assert out['ret'].numel() == 0
+
+
+def test_stop_on_done_false_and_long_horizon_failures(eng, orc):
+    """ rollout(stop_on_done=False): the env keeps stepping after done, the final reward is given once. """
+    kind = abi.ENV_OMO
+    case = cases.make_case(kind, 128, seed=3, policy='linear', scale=3.0)
+    _compare_rollouts(eng, orc, case, T=120, flags=0)
+    _compare_rollouts(eng, orc, case, T=120, flags=abi.F_STOP_ON_DONE)
+
+
+def test_nan_actions_are_flagged_not_fatal(eng, orc):
+    kind = abi.ENV_BOB
+    case = cases.make_case(kind, 64, seed=9, policy='linear')
+    params = case['params'].copy()
+    params[0] = np.nan
+    ref = orc.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], params, case['init'], case['dp'])
+    out = eng.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], params, case['init'], case['dp'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)

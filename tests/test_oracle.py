@@ -1,0 +1,248 @@
+"""
+CPU tests of the oracle (test infrastructure): the reference's own known-answer tests for this path, hand-derivable
+anchors from the reference source, agreement of the two independent restatements (C and NumPy), and the committed
+golden vectors.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as orc, pysim_oracle_np as onp
+from simurlacra_amd import _abi as abi, envdefs
+from simurlacra_amd.specs import TaskSpec, PolicySpec
+from tests import cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ------------------------------------------------------------------ known-answer tests held by the reference
+def test_kat_modulated_rew_fcn_numpy():
+    """ Pyrado/tests/test_tasks.py:44-61 """
+    s, a = np.array([1., 2., 3., 4.]), np.array([0., 0.])
+    t = onp.Task(np.zeros(4), 'quadr', np.eye(4), np.eye(2), radial_idcs=[0, 1, 3], mod=2)
+    assert t.step_rew(s, a) == -(1**2 + 3**2)
+    t = onp.Task(np.zeros(4), 'quadr', np.eye(4), np.eye(2), radial_idcs=[1, 3], mod=np.array([2, 3]))
+    assert t.step_rew(s, a) == -(1**2 + 3**2 + 1**2)
+
+
+def test_kat_modulated_rew_fcn_c():
+    """ Same numbers through the C restatement: the 4-dim case embedded in the 8-dim QBB state (zeros elsewhere). """
+    s = np.array([1., 2., 3., 4., 0., 0., 0., 0.])
+    a = np.zeros(2)
+    dp = np.array(list(envdefs.nominal_domain_param(abi.ENV_QBB).values()))
+    t = TaskSpec(np.zeros(8), 'quadr', np.eye(8), np.eye(2), radial_idcs=[0, 1, 3], mod=[2, 2, 2])
+    assert orc.step_rew(abi.ENV_QBB, t.to_c(8, 2), dp, s, a) == -(1**2 + 3**2)
+    t = TaskSpec(np.zeros(8), 'quadr', np.eye(8), np.eye(2), radial_idcs=[1, 3], mod=[2, 3])
+    assert orc.step_rew(abi.ENV_QBB, t.to_c(8, 2), dp, s, a) == -(1**2 + 3**2 + 1**2)
+
+
+def test_kat_final_reward_yields_once():
+    """ FinalRewTask gives its reward once per reset (Pyrado/tests/test_tasks.py:181-188,252-259), here on the failure
+    branch of OneMassOscillatorSim's task: -1000 when the state leaves the box, nothing afterwards. """
+    kind = abi.ENV_OMO
+    dp = np.array(list(envdefs.nominal_domain_param(kind).values()))[:, None]
+    task_c = envdefs.default_task_spec(kind).to_c(2, 1)
+    mem = orc.reset(kind, 0.01, 1000, task_c, np.array([[0.999], [9.0]]), dp)
+    act = np.zeros((1, 1))
+    _, r1, d1, st1, _ = orc.step(kind, 0.01, 1000, task_c, mem, act, dp)
+    assert d1[0] == 1 and st1[0] & abi.ST_FAILED
+    step_only = -(10*0.999**2 + 0.01*81.)
+    assert r1[0] == pytest.approx(step_only - 1000., rel=1e-14)
+    s_before = mem['state'].copy()
+    _, r2, d2, _, _ = orc.step(kind, 0.01, 1000, task_c, mem, act, dp)
+    assert d2[0] == 1
+    assert r2[0] == pytest.approx(-(10*s_before[0, 0]**2 + 0.01*s_before[1, 0]**2), rel=1e-14)  # no second -1000
+
+
+# ------------------------------------------------------------------------ anchors derivable from the source
+def test_anchor_qq_constants():
+    """ quanser_qube.py:62-90 with the nominal parameters """
+    dp = np.array(list(envdefs.nominal_domain_param(abi.ENV_QQ).values()))
+    c = orc.constants(abi.ENV_QQ, dp)[0]
+    Mr, Lr, Mp, Lp, g = 0.095, 0.085, 0.024, 0.129, 9.81
+    exp = [Mr*Lr**2/12 + Mp*Lr**2, 0.25*Mp*Lp**2, 0.5*Mp*Lp*Lr, Mp*Lp**2/12 + 0.25*Mp*Lp**2, 0.5*Mp*Lp*g]
+    np.testing.assert_allclose(c[:5], exp, rtol=1e-15)
+    np.testing.assert_allclose(c[:5], [2.30597916e-4, 9.9846e-5, 1.3158e-4, 1.33128e-4, 1.518588e-2], rtol=1e-6)
+
+
+def test_anchor_omo_one_euler_step():
+    """ one_mass_oscillator.py:75-84: from [-0.7, 0], u = 0, nominal (m=1, k=30, d=0.5), dt = 0.01 -> [-0.7, 0.21] """
+    kind = abi.ENV_OMO
+    dp = np.array([[1.], [30.], [0.5]])
+    task_c = envdefs.default_task_spec(kind).to_c(2, 1)
+    mem = orc.reset(kind, 0.01, 100, task_c, np.array([[-0.7], [0.]]), dp)
+    obs, rew, done, st, _ = orc.step(kind, 0.01, 100, task_c, mem, np.zeros((1, 1)), dp)
+    np.testing.assert_allclose(obs[:, 0], [-0.7, 0.21], rtol=1e-13)
+    assert rew[0] == pytest.approx(-(10*0.49), rel=1e-14) and done[0] == 0
+
+
+@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_OMO])
+def test_anchor_zero_state_zero_action_is_a_fixed_point(kind):
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    dp = np.array(list(envdefs.nominal_domain_param(kind).values()))[:, None]
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    mem = orc.reset(kind, 0.01, 100, task_c, np.zeros((S, 1)), dp)
+    orc.step(kind, 0.01, 100, task_c, mem, np.zeros((A, 1)), dp)
+    assert np.all(mem['state'] == 0.)
+
+
+def test_anchor_qq_rk4_uses_unadvanced_accelerations():
+    """ quanser_qube.py:128-142: with the accelerations frozen at the start state, one step from s gives
+    s + dt*[thd + dt/2*thdd, ald + dt/2*aldd, thdd, aldd] exactly (sum of the four stages). """
+    kind, dt = abi.ENV_QQ, 0.004
+    dp = np.array(list(envdefs.nominal_domain_param(kind).values()))
+    task_c = envdefs.default_task_spec(kind).to_c(4, 1)
+    s0 = np.array([0.3, -0.5, 1.1, -2.0])
+    env = onp.NpEnv('qq', dt, 10)
+    env.reset(s0.copy())
+    c = env.c
+    th, al, thd, ald = s0
+    u = 1.5
+    a = c[0] + c[1]*np.sin(al)**2; b = c[2]*np.cos(al); det = a*c[3] - b*b
+    trq = dp[2]*(u - dp[2]*thd)/dp[1]
+    c0 = c[1]*np.sin(2*al)*thd*ald - c[2]*np.sin(al)*ald*ald
+    c1 = -0.5*c[1]*np.sin(2*al)*thd*thd + c[4]*np.sin(al)
+    x = trq - dp[5]*thd - c0; y = -dp[8]*ald - c1
+    thdd, aldd = (c[3]*x - b*y)/det, (a*y - b*x)/det
+    expect = s0 + dt*np.array([thd + dt/2*thdd, ald + dt/2*aldd, thdd, aldd])
+    mem = orc.reset(kind, dt, 10, task_c, s0[:, None], dp[:, None])
+    orc.step(kind, dt, 10, task_c, mem, np.array([[u]]), dp[:, None])
+    np.testing.assert_allclose(mem['state'][:, 0], expect, rtol=1e-13)
+
+
+def test_qbb_dead_zone_is_written_into_in_bounds_actions_only():
+    """ spaces/box.py:144-148 + quanser_ball_balancer.py:212-215: an action inside its bounds is the array the
+    dynamics zero in place; a clipped action is a copy, so the caller's array keeps the raw value. """
+    kind = abi.ENV_QBB
+    dp = np.array(list(envdefs.nominal_domain_param(kind).values()))[:, None].repeat(2, axis=1)
+    task_c = envdefs.default_task_spec(kind).to_c(8, 2)
+    init = np.array([[0.1, 0.1], [0., 0.], [0., 0.], [0., 0.]])
+    mem = orc.reset(kind, 0.01, 100, task_c, init, dp)
+    act = np.array([[0.2, 0.2], [-0.05, 5.0]])  # env 0: both in the dead zone; env 1: second component out of bounds
+    _, _, _, _, a_out = orc.step(kind, 0.01, 100, task_c, mem, act, dp)
+    np.testing.assert_array_equal(a_out[:, 0], [0., 0.])
+    np.testing.assert_array_equal(a_out[:, 1], [0.2, 5.0])
+
+
+def test_qbb_ik_c_vs_numpy():
+    for th in np.linspace(-np.pi/2.1, np.pi/2.1, 9):
+        a, b = orc.qbb_ik(th, 0.0254, 0.275), onp.qbb_ik(th, 0.0254, 0.275)
+        assert np.isfinite(a) and a == pytest.approx(b, abs=1e-13)
+
+
+# ----------------------------------------------------------------------------------- C vs NumPy restatement
+@pytest.mark.parametrize('kind', cases.KINDS)
+@pytest.mark.parametrize('pol', ['linear', 'fnn'])
+def test_c_and_numpy_restatements_agree(kind, pol):
+    case = cases.make_case(kind, 5, seed=31 + kind, policy=pol)
+    T = 80
+    ps, params = case['ps'], case['params']
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], ps, params, case['init'], case['dp'], record=True)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(5):
+        env = onp.NpEnv(cases.KIND_NAMES[kind], case['dt'], T)
+        policy = (onp.LinearPolicyNp(ps.feats, params.reshape(ps.act_dim, -1)) if pol == 'linear'
+                  else onp.FNNPolicyNp(ps.obs_dim, ps.hidden, ps.act_dim, params))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['obs'][:L + 1, :, i], ro['observations']) < 1e-13
+        assert cases.rel_err(out['act'][:L, :, i], ro['actions']) < 1e-13
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-13
+        assert out['ret'][i] == pytest.approx(ro['ret'], rel=1e-13, abs=1e-13)
+
+
+def test_c_and_numpy_agree_with_action_delay_on_qbb():
+    """ ActDelayWrapper queues array objects, so the QBB dead zone lands in the action recorded `delay` steps ago. """
+    kind, T, delay = abi.ENV_QBB, 30, 3
+    case = cases.make_case(kind, 3, seed=77, policy='linear', scale=0.2)
+    dp = np.vstack([case['dp'], np.full((1, 3), float(delay))])
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], dp, record=True,
+                      act_delay_row=20)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(3):
+        env = onp.NpEnv('qbb', case['dt'], T)
+        policy = onp.LinearPolicyNp(case['ps'].feats, case['params'].reshape(2, -1))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])), act_delay=delay)
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['act'][:L, :, i], ro['actions']) < 1e-13
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-13
+
+
+def test_oracle_policy_forward_matches_torch():
+    """ FNN.forward / LinearPolicy.forward against torch.nn.Linear in fp64 (policies/fnn.py:129-151) """
+    import torch
+    rng = np.random.default_rng(3)
+    ps = PolicySpec('fnn', 6, 1, hidden=[64, 64], hidden_nonlin=['tanh', 'tanh'])
+    params = rng.standard_normal(ps.num_param)
+    obs = rng.standard_normal(6)
+    lin = [torch.nn.Linear(6, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 1)]
+    net = torch.nn.Sequential(lin[0], torch.nn.Tanh(), lin[1], torch.nn.Tanh(), lin[2]).double()
+    torch.nn.utils.vector_to_parameters(torch.as_tensor(params), net.parameters())
+    with torch.no_grad():
+        ref = net(torch.as_tensor(obs)).numpy()
+    np.testing.assert_allclose(orc.policy_forward(ps, params, obs), ref, rtol=1e-12, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'rollout_*.npz'))), ids=os.path.basename)
+def test_c_oracle_reproduces_golden_vectors(path):
+    g = np.load(path)
+    kind, T = int(g['kind']), int(g['T'])
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    if len(g['hidden']) == 0:
+        ps = PolicySpec('linear', O, A, feats=[str(f) for f in g['feats']])
+    else:
+        ps = PolicySpec('fnn', O, A, hidden=[int(h) for h in g['hidden']], hidden_nonlin=['tanh']*len(g['hidden']))
+    out = orc.rollout(kind, float(g['dt']), T, task_c, ps, g['params'], g['init'], g['dp'], record=True)
+    np.testing.assert_array_equal(out['length'], g['length'])
+    for k in ('obs', 'act', 'rew', 'ret'):
+        assert cases.rel_err(out[k], g[k]) < 1e-13, k
+
+
+# ------------------------------------------------------------------------------- the product's device RNG
+def test_philox_known_answers():
+    """ Philox4x32-10 vectors of the Random123 distribution (kat_vectors) """
+    assert orc.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox([0xffffffff]*4, [0xffffffff]*2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_randomize_distributions_and_clipping():
+    n = 200000
+    nominal = [1., 2., 3., 4.]
+    distrs = [dict(kind=abi.DISTR_NORMAL, row=0, a=5., b=2., clip_lo=1.5),
+              dict(kind=abi.DISTR_UNIFORM, row=1, a=3., b=1.),
+              dict(kind=abi.DISTR_BERNOULLI, row=2, a=-1., b=7., c=0.7),
+              dict(kind=abi.DISTR_UNIFORM, row=3, a=5., b=5., clip_lo=0, roundint=1)]
+    x = orc.randomize(n, distrs, nominal, seed=9)
+    assert x[0].min() == 1.5 and abs(np.mean(x[0][x[0] > 1.5]) - 5.) < 0.2 and abs(np.median(x[0]) - 5.) < 0.03
+    assert 2. <= x[1].min() and x[1].max() < 4. and abs(x[1].mean() - 3.) < 0.01
+    assert set(np.unique(x[2])) == {-1., 7.} and abs((x[2] == 7.).mean() - 0.7) < 0.01
+    assert np.all(x[3] == np.round(x[3])) and x[3].min() == 0 and x[3].max() == 10
+    # counter-based: env i gets the same value whatever the batch it is drawn in
+    y = orc.randomize(1000, distrs, nominal, seed=9, env_offset=5000)
+    np.testing.assert_array_equal(y, x[:, 5000:6000])
+
+
+def test_sample_init_lies_in_each_init_space():
+    for kind in cases.KINDS:
+        rng = np.random.default_rng(kind)
+        dp = cases.domain_params(kind, 2000, rng)
+        x = orc.sample_init(kind, 2000, dp, seed=3)
+        if kind == abi.ENV_QBB:
+            r = np.hypot(x[0], x[1])
+            assert np.all(r >= 0.75*dp[3]/2*(1 - 1e-12)) and np.all(r <= 0.8*dp[3]/2*(1 + 1e-12))
+            assert np.all(np.abs(x[2:]) <= 0.025)
+        elif kind == abi.ENV_BOB:
+            assert np.all(np.abs(x[0]) >= 0.7*dp[4]/2*(1 - 1e-12)) and np.all(np.abs(x[0]) <= 0.8*dp[4]/2*(1 + 1e-12))
+            assert 0.4 < (x[0] > 0).mean() < 0.6
+        elif kind == abi.ENV_OMO:
+            assert np.all((x[0] >= -0.75) & (x[0] <= -0.65) & (np.abs(x[1]) <= 0.1))
+        elif kind == abi.ENV_QQ:
+            assert np.all(np.abs(x) <= (np.array([2, 1, .5, .5])/180*np.pi)[:, None])
