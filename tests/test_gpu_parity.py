@@ -139,7 +139,7 @@ def test_segment_mean(eng):
     import torch
     ret = torch.randn(37*10, dtype=torch.float64, device=eng.device)
     got = eng.segment_mean(ret, 10).cpu().numpy()
-    np.testing.assert_allclose(got, ret.view(37, 10).mean(dim=1).cpu().numpy(), rtol=1e-14)
+    np.testing.assert_allclose(got, ret.view(37, 10).mean(dim=1).cpu().numpy(), rtol=1e-12, atol=1e-15)
 
 
 def test_buffer_mode_and_population_mode(eng, orc):
