@@ -1,0 +1,6 @@
+from .base import EnvWrapper, EnvWrapperAct, EnvWrapperObs
+from .action_delay import ActDelayWrapper
+from .action_normalization import ActNormWrapper
+from .domain_randomization import (DomainRandWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive,
+                                   MetaDomainRandWrapper, remove_all_dr_wrappers)
+from .utils import all_envs, attr_env, attr_env_get, inner_env, remove_env, typed_env

