@@ -86,7 +86,8 @@ def test_rollout_fused_equals_stepwise_equals_oracle(name):
     for a, b, c in ((ro.observations, ro2.observations, ref['observations']), (ro.actions, ro2.actions, ref['actions']),
                     (ro.rewards, ro2.rewards, ref['rewards']), (ro.env_infos['t'], ro2.env_infos['t'], ref['t'])):
         assert cases.rel_err(a, c) <= TOL and cases.rel_err(b, c) <= TOL
-    assert ro.done[-1] and ro.rollout_info['domain_param']['g'] == pytest.approx(dp_dict['g'])
+    k0 = next(iter(dp_dict))
+    assert ro.done[-1] and ro.rollout_info['domain_param'][k0] == pytest.approx(dp_dict[k0])
     assert float(ro.undiscounted_return()) == pytest.approx(ref['ret'], rel=1e-9)
 
 
