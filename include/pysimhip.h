@@ -303,6 +303,12 @@ int psh_qbb_ik(psh_ctx* ctx, int32_t n, const double* th /*[dev][n]*/, const dou
 int psh_segment_mean(psh_ctx* ctx, int32_t n_groups, int32_t group_size, const double* ret /*[dev]*/,
                      double* mean /*[dev][n_groups]*/, void* stream);
 
+/* Diagnostic, no counterpart in the reference: evaluates one of the device's fp64 elementary functions
+ * (the ones the step loop uses in place of NumPy's np.exp / np.tanh / np.sin / np.cos / np.fmod) element-wise, so that
+ * their accuracy can be tested directly.  fn: 0 exp, 1 tanh, 2 sigmoid, 3 sin, 4 cos, 5 fmod(x[i], m[i]). */
+int psh_eval_math(psh_ctx* ctx, int32_t fn, int32_t n, const double* x /*[dev][n]*/, const double* m /*[dev][n] or NULL*/,
+                  double* y /*[dev][n]*/, void* stream);
+
 /* Elapsed time of the most recent psh_rollout kernel of this ctx in milliseconds, measured with HIP
  * events on the launch stream; synchronises on the stop event.  Returns < 0 if none was recorded. */
 float psh_last_rollout_ms(psh_ctx* ctx);

@@ -120,4 +120,5 @@ PSH_SYMBOLS = {
     'psh_qbb_ik': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'psh_segment_mean': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'psh_last_rollout_ms': (C.c_float, [C.c_void_p]),
+    'psh_eval_math': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/pysimhip.h"
+#include "psh_math.h"
 
 #define PSH_PI 3.141592653589793
 #define PSH_DEV __device__ __forceinline__
@@ -48,7 +49,7 @@ template <> struct Env<PSH_ENV_QQ> {
         for (int i = 0; i < 4; ++i) { lo[i] = -m[i]; hi[i] = m[i]; }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -max_volt; hi[0] = max_volt; }
-    PSH_DEV void refresh() { sincos(s[0], &sth, &cth); sincos(s[1], &sal, &cal); }
+    PSH_DEV void refresh() { psh_sincos(s[0], &sth, &cth); psh_sincos(s[1], &sal, &cal); }
     PSH_DEV void reset(const double* init, int, bool) {
         for (int i = 0; i < 4; ++i) s[i] = init[i];
         refresh();
@@ -119,7 +120,7 @@ template <int KIND> struct EnvQCP {
         }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -8.; hi[0] = 8.; }
-    PSH_DEV void refresh() { sincos(s[1], &sth, &cth); }
+    PSH_DEV void refresh() { psh_sincos(s[1], &sth, &cth); }
     PSH_DEV void reset(const double* init, int, bool) {
         for (int i = 0; i < 4; ++i) s[i] = init[i];
         refresh();
@@ -216,8 +217,8 @@ template <> struct Env<PSH_ENV_QBB> {
         const double th_x_ddot = (A_m * act[0] - B_eq_v * th_x_dot) / J_eq;
         const double th_y_ddot = (A_m * act[1] - B_eq_v * th_y_dot) / J_eq;
         double sx, cx, sy, cy, sa, ca, sb, cb;
-        sincos(th_x, &sx, &cx); sincos(th_y, &sy, &cy);
-        sincos(plate[0], &sa, &ca); sincos(plate[1], &sb, &cb);
+        psh_sincos(th_x, &sx, &cx); psh_sincos(th_y, &sy, &cy);
+        psh_sincos(plate[0], &sa, &ca); psh_sincos(plate[1], &sb, &cb);
         const double a_dot = c_kin * th_x_dot * cx / ca;
         const double b_dot = c_kin * -th_y_dot * cy / cb;  // cos(-th_y) = cos(th_y)
         const double r2 = r_ball * r_ball;
@@ -268,7 +269,7 @@ template <> struct Env<PSH_ENV_BOB> {
     PSH_DEV void dynamics(double* act, double dt, bool) {
         const double x = s[0], a = s[1] + ang_offset, x_dot = s[2], a_dot = s[3];
         double sa, ca;
-        sincos(a, &sa, &ca);
+        psh_sincos(a, &sa, &ca);
         const double zeta_beam = m_ball * (x * x) + J_beam;
         const double x_ddot = (-c_frict * x_dot + m_ball * x * (a_dot * a_dot) - m_ball * g * sa) / zeta_ball;
         const double a_ddot = (act[0] - 2. * m_ball * x * x_dot * a_dot - m_ball * g * ca * x) / zeta_beam;
@@ -345,7 +346,7 @@ template <int KIND> PSH_DEV double step_rew(const psh_task& t, double c_max, con
     if (t.radial) {
 #pragma unroll
         for (int i = 0; i < S; ++i)
-            if (t.radial_mask & (1 << i)) es[i] = fmod(es[i], t.mod[i]);
+            if (t.radial_mask & (1 << i)) es[i] = psh_fmod(es[i], t.mod[i]);
         // the +-pi fold touches EVERY error component (desired_state.py:125-126), velocities included
 #pragma unroll
         for (int i = 0; i < S; ++i) {
@@ -359,8 +360,8 @@ template <int KIND> PSH_DEV double step_rew(const psh_task& t, double c_max, con
     for (int i = 0; i < A; ++i) ea[i] = -act[i];
     switch (t.rew_kind) {
     case PSH_REW_QUADR: return -quadr_cost<S, A>(t, es, ea);
-    case PSH_REW_EXP_QUADR: return exp(-quadr_cost<S, A>(t, es, ea));
-    case PSH_REW_SCALED_EXP_QUADR: return exp(-c_max * quadr_cost<S, A>(t, es, ea));
+    case PSH_REW_EXP_QUADR: return psh_exp(-quadr_cost<S, A>(t, es, ea));
+    case PSH_REW_SCALED_EXP_QUADR: return psh_exp(-c_max * quadr_cost<S, A>(t, es, ea));
     default: {  // PSH_REW_SWINGUP
         double eth = es[0], ex = es[0];
 #pragma unroll

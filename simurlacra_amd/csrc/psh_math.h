@@ -1,0 +1,125 @@
+// fp64 elementary functions for the step loop, written for the argument ranges the simulations produce: a few ulp
+// accurate, branch-free on the common path, and several times cheaper than the general-purpose library versions
+// (which carry huge-argument reduction, double-double exponentials and loop-based fmod).  Arguments outside the
+// fast range fall back to the library routine, so results stay defined everywhere.
+//
+// Polynomial kernels: the classic minimax coefficients of the Sun/fdlibm sin/cos kernels and the Taylor series of
+// exp on |r| <= ln2/2 (truncation below 2^-57).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#define PSH_MATH __device__ __forceinline__
+
+// d in [0.5, 4]: reciprocal refined to full precision (the hardware estimate plus two Newton steps)
+PSH_MATH double psh_rcp_refined(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// n / d for moderate d (no scaling needed): one correction step after the refined reciprocal
+PSH_MATH double psh_div_moderate(double n, double d) {
+    const double r = psh_rcp_refined(d);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// exp(x) - 1 split as (k, q): exp(x) = 2^k * (1 + q), |q| <= 0.42.  Shared by exp, tanh and sigmoid.
+PSH_MATH double psh_exp_poly(double x, int& k) {
+    const double kd = rint(x * 1.4426950408889634074);
+    k = (int)kd;
+    double r = fma(-kd, 6.93147180369123816490e-01, x);   // ln2 high part (33 bits): the product is exact
+    r = fma(-kd, 1.90821492927058770002e-10, r);          // ln2 low part
+    // q = r + r^2/2! + ... + r^13/13!
+    double p = 1.6059043836821613e-10;                     // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                  // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                  // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                 // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                   // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                  // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);                  // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                  // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                 // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    return p * r;
+}
+
+PSH_MATH double psh_exp(double x) {
+    x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
+    x = (x > 710.0) ? 710.0 : x;     // above this exp overflows to +inf
+    int k;
+    const double q = psh_exp_poly(x, k);
+    return ldexp(1.0 + q, k);
+}
+
+PSH_MATH double psh_tanh(double x) {
+    const double a = fabs(x);
+    double y = -2.0 * a;
+    y = (y < -80.0) ? -80.0 : y;     // tanh is 1 to the last bit long before; keeps k small
+    int k;
+    const double q = psh_exp_poly(y, k);
+    // E = exp(-2a) - 1 without cancellation: for k == 0 it is q itself
+    const double E = (k == 0) ? q : (ldexp(1.0 + q, k) - 1.0);
+    const double t = psh_div_moderate(-E, 2.0 + E);   // (1 - e)/(1 + e), denominator in (1, 2]
+    return copysign(t, x);
+}
+
+PSH_MATH double psh_sigmoid(double x) {
+    // 1/(1 + exp(-x)); for x < 0 use exp(x)/(1 + exp(x)) so that the exponential never overflows
+    const double e = psh_exp(-fabs(x));
+    const double s = psh_div_moderate(1.0, 1.0 + e);  // sigmoid(|x|)
+    return (x >= 0.0) ? s : psh_div_moderate(e, 1.0 + e);
+}
+
+// sin and cos together.  Cody-Waite reduction by pi/2 in three parts, exact for |x| <= 1e5; larger or non-finite
+// arguments take the library path.
+PSH_MATH void psh_sincos(double x, double* s, double* c) {
+    if (!(fabs(x) <= 1.0e5)) {
+        sincos(x, s, c);
+        return;
+    }
+    const double nd = rint(x * 6.36619772367581382433e-01);  // 2/pi
+    const int n = (int)nd;
+    double r = fma(-nd, 1.57079632673412561417e+00, x);      // pi/2, first 33 bits
+    r = fma(-nd, 6.07710050630396597660e-11, r);             // next 33 bits
+    r = fma(-nd, 2.02226624879595063154e-21, r);             // tail
+    const double z = r * r;
+    // sin kernel on [-pi/4, pi/4]
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sn = fma(ps * z, r, r);
+    // cos kernel on [-pi/4, pi/4]
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cs = fma(pc * z, z, fma(-0.5, z, 1.0));
+    const double ss = (n & 1) ? cs : sn;
+    const double cc = (n & 1) ? sn : cs;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// C fmod (sign of x, exact) for quotients below 2^52; library path otherwise
+PSH_MATH double psh_fmod(double x, double m) {
+    const double am = fabs(m);
+    const double qd = x / am;
+    if (!(fabs(qd) < 4503599627370496.0) || am == 0.0) return fmod(x, m);
+    const double q = trunc(qd);
+    double r = fma(-q, am, x);
+    // x / am may have rounded up to the next integer: the remainder then has the wrong sign
+    if (x > 0.0 && r < 0.0) r += am;
+    if (x < 0.0 && r > 0.0) r -= am;
+    return (r == 0.0) ? copysign(0.0, x) : r;
+}

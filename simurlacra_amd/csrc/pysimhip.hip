@@ -57,9 +57,9 @@ struct RolloutArgs {
 // ------------------------------------------------------------------------------------------------ math helpers
 PSH_DEV double nl_apply(int nl, double v) {
     switch (nl) {
-    case PSH_NL_TANH: return tanh(v);
+    case PSH_NL_TANH: return psh_tanh(v);
     case PSH_NL_RELU: return v > 0. ? v : 0.;
-    case PSH_NL_SIGMOID: return 1. / (1. + exp(-v));
+    case PSH_NL_SIGMOID: return psh_sigmoid(v);
     default: return v;
     }
 }
@@ -70,12 +70,12 @@ PSH_DEV double feat_apply(int id, double x) {
     case PSH_FEAT_ABS: return fabs(x);
     case PSH_FEAT_SQUARED: return x * x;
     case PSH_FEAT_CUBED: return x * x * x;
-    case PSH_FEAT_SIG: return 1. / (1. + exp(-x));
-    case PSH_FEAT_BELL: return exp(-(x * x));
-    case PSH_FEAT_SIN: return sin(x);
-    case PSH_FEAT_COS: return cos(x);
-    case PSH_FEAT_SINSIN: { const double s = sin(x); return s * s; }
-    case PSH_FEAT_SINCOS: { double s, c; sincos(x, &s, &c); return s * c; }
+    case PSH_FEAT_SIG: return psh_sigmoid(x);
+    case PSH_FEAT_BELL: return psh_exp(-(x * x));
+    case PSH_FEAT_SIN: { double s, c; psh_sincos(x, &s, &c); return s; }
+    case PSH_FEAT_COS: { double s, c; psh_sincos(x, &s, &c); return c; }
+    case PSH_FEAT_SINSIN: { double s, c; psh_sincos(x, &s, &c); return s * s; }
+    case PSH_FEAT_SINCOS: { double s, c; psh_sincos(x, &s, &c); return s * c; }
     default: return x;  // identity
     }
 }
@@ -529,6 +529,21 @@ __global__ __launch_bounds__(256) void k_segment_mean(int n_groups, int group_si
     if (lane == 0) mean[g] = acc / group_size;
 }
 
+// element-wise evaluation of the device math functions (accuracy tests)
+__global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* x, const double* m, double* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    switch (fn) {
+    case 0: y[i] = psh_exp(x[i]); break;
+    case 1: y[i] = psh_tanh(x[i]); break;
+    case 2: y[i] = psh_sigmoid(x[i]); break;
+    case 3: psh_sincos(x[i], &s, &c); y[i] = s; break;
+    case 4: psh_sincos(x[i], &s, &c); y[i] = c; break;
+    default: y[i] = psh_fmod(x[i], m[i]);
+    }
+}
+
 // =================================================================================================== C ABI
 static bool dims_of(int kind, int32_t d[5]) {
     switch (kind) {
@@ -820,6 +835,15 @@ extern "C" int psh_segment_mean(psh_ctx* c, int32_t n_groups, int32_t group_size
     if (n_groups == 0) return PSH_OK;
     PSH_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_segment_mean, dim3((n_groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_groups, group_size, ret, mean);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_eval_math(psh_ctx* c, int32_t fn, int32_t n, const double* x, const double* m, double* y, void* stream) {
+    if (!c || fn < 0 || fn > 5 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
+    if (n == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_eval_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)fn, (int)n, x, m, y);
     PSH_HIP(c, hipGetLastError());
     return PSH_OK;
 }

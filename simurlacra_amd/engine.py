@@ -210,6 +210,16 @@ class Engine:
                                         self._stream()), 'psh_qbb_ik')
         return ang
 
+    def eval_math(self, fn: str, x, m=None):
+        """ Element-wise device math (diagnostic): fn in exp, tanh, sigmoid, sin, cos, fmod. """
+        ids = dict(exp=0, tanh=1, sigmoid=2, sin=3, cos=4, fmod=5)
+        x = self.f64(x).reshape(-1)
+        m = None if m is None else self.f64(m).reshape(-1)
+        y = torch.empty_like(x)
+        self._check(self.lib.psh_eval_math(self._h, ids[fn], x.numel(), _ptr(x), _ptr(m), _ptr(y), self._stream()),
+                    'psh_eval_math')
+        return y
+
     def segment_mean(self, ret, group_size):
         ret = self.f64(ret).reshape(-1)
         n_groups = ret.numel()//group_size

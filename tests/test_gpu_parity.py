@@ -188,3 +188,33 @@ def test_nan_actions_are_flagged_not_fatal(eng, orc):
     np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
     np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
     assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)
+
+
+def _ulp_err(got, ref):
+    return np.abs(got - ref)/np.spacing(np.abs(ref))
+
+
+def test_device_math_accuracy(eng):
+    """ The step loop's own fp64 exp/tanh/sigmoid/sin/cos/fmod against libm (NumPy): a few ulp on the ranges the
+    simulations produce, exact for fmod, library behaviour outside the fast range. """
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-2, 2, 20000), [0., -0., 1e-300, -745.2, 709.7]])
+    assert _ulp_err(eng.eval_math('exp', x).cpu().numpy(), np.exp(x)).max() <= 2
+    x = np.concatenate([rng.uniform(-25, 25, 20000), rng.uniform(-1, 1, 20000), 10.**rng.uniform(-12, 0, 5000), [0., 40., -40.]])
+    got, ref = eng.eval_math('tanh', x).cpu().numpy(), np.tanh(x)
+    assert _ulp_err(got[ref != 0], ref[ref != 0]).max() <= 4 and np.all(got[ref == 0] == 0)
+    x = np.concatenate([rng.uniform(-40, 40, 20000), [0., 800., -800.]])
+    got, ref = eng.eval_math('sigmoid', x).cpu().numpy(), 1/(1 + np.exp(-x))
+    assert np.abs(got - ref).max() <= 3e-16 and _ulp_err(got[np.abs(x) < 30], ref[np.abs(x) < 30]).max() <= 4
+    x = np.concatenate([rng.uniform(-100, 100, 40000), rng.uniform(-1e5, 1e5, 10000), [0., 1e7, -3e9, np.pi, np.pi/2]])
+    for fn, f in (('sin', np.sin), ('cos', np.cos)):
+        got, ref = eng.eval_math(fn, x).cpu().numpy(), f(x)
+        assert np.abs(got - ref).max() <= 2.5e-16, fn
+    xs = np.concatenate([rng.uniform(-50, 50, 20000), [-2., -4., 4., 2*np.pi, -6*np.pi, 7., 0., 1e300]])
+    ms = np.concatenate([rng.choice([2*np.pi, 2., 3., 0.37], 20000), [2., 3., 2., 2*np.pi, 2*np.pi, 7., 2., 2*np.pi]])
+    got, ref = eng.eval_math('fmod', xs, ms).cpu().numpy(), np.fmod(xs, ms)
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(np.signbit(got), np.signbit(ref))
+    nan_in = np.array([np.nan, np.inf, -np.inf])
+    assert np.all(np.isnan(eng.eval_math('tanh', nan_in).cpu().numpy()) == [True, False, False])
+    assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
