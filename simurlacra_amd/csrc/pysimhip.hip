@@ -23,9 +23,16 @@ struct psh_ctx {
     char err[512];
     double* wfrag;       // packed FNN weights (fragment layout), grown on demand
     size_t wfrag_doubles;
+    double* plate;       // QBB plate angles of the IK prologue [2, N], grown on demand
+    size_t plate_doubles;
+    unsigned int* queue; // work-queue counter of the rollout kernels
+    int num_cus;
     hipEvent_t ev0, ev1;
     int timed;
 };
+
+// grow-only device scratch owned by the context
+static int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t need);
 
 static void set_err(psh_ctx* c, const char* fmt, const char* a = "", const char* b = "") {
     if (c) snprintf(c->err, sizeof c->err, fmt, a, b);
@@ -40,6 +47,25 @@ static void set_err(psh_ctx* c, const char* fmt, const char* a = "", const char*
         }                                                                     \
     } while (0)
 
+static int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t need) {
+    if (need <= *have) return PSH_OK;
+    if (*buf) PSH_HIP(c, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    PSH_HIP(c, hipMalloc(buf, need * sizeof(double)));
+    *have = need;
+    return PSH_OK;
+}
+
+// Persistent launch: as many workgroups as the device keeps resident (lanes pull envs from the queue), fewer when the
+// batch is smaller than that.
+template <class K> static unsigned persistent_grid(psh_ctx* c, K kernel, int block, size_t lds_bytes, int n_envs) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    const long resident = (long)per_cu * c->num_cus;
+    const long need = ((long)n_envs + block - 1) / block;
+    return (unsigned)(need < resident ? need : resident);
+}
+
 // ------------------------------------------------------------------------------------------ kernel arguments
 struct RolloutArgs {
     int n_envs, max_steps, flags, init_dim;
@@ -52,6 +78,8 @@ struct RolloutArgs {
     int lds_doubles;       // FNN: doubles of the packed weight image
     const double* wfrag;   // FNN: packed weight image (device)
     double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
+    unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
+    const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
 };
 
 // ------------------------------------------------------------------------------------------------ math helpers
@@ -85,23 +113,43 @@ template <int KIND> struct Lane {
     using E = Env<KIND>;
     E e;
     double c_max, ret;
+    long i;           // env this lane currently runs, -1: none
     int curr_step, yielded, st, k;
     bool done, live;  // live: this lane still has steps to execute
+    bool exhausted;   // the work queue had nothing left for this lane
 
-    PSH_DEV void load(const RolloutArgs& a, long i) {
+    PSH_DEV void init() { i = -1; live = false; exhausted = false; }
+
+    // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
+    // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
+    // an env has no influence on its results.
+    PSH_DEV void turnover(const RolloutArgs& a) {
+        if (i >= 0 && !live) { store(a); i = -1; }
+        if (i < 0 && !exhausted) {
+            const unsigned int nxt = atomicAdd(a.queue, 1u);
+            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a); } else { exhausted = true; }
+        }
+    }
+
+    PSH_DEV void load(const RolloutArgs& a) {
         const long col = a.dp_index ? (long)a.dp_index[i] : i;
         const DpCol p{a.domain_param, a.ld_dp, col};
         e.setup(p);
         c_max = task_c_max<KIND>(e, a.task);
         double init[E::S];
         for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * a.ld_init + i] : 0.;
-        e.reset(init, a.init_dim, (a.flags & PSH_F_SIMPLIFIED_DYN) != 0);
+        if constexpr (KIND == PSH_ENV_QBB) {
+            e.reset(init, a.init_dim, true);  // plate angles come from the IK prologue kernel
+            if (a.plate) { e.plate[0] = a.plate[i]; e.plate[1] = a.plate[(long)a.n_envs + i]; }
+        } else {
+            e.reset(init, a.init_dim, false);
+        }
         ret = 0.; curr_step = 0; yielded = 0; st = 0; k = 0; done = false;
         live = a.max_steps > 0;
     }
 
     // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
-    PSH_DEV void pre_policy(const RolloutArgs& a, long i, double* obs) {
+    PSH_DEV void pre_policy(const RolloutArgs& a, double* obs) {
         e.observe(obs);
         bool nan = false;
 #pragma unroll
@@ -113,7 +161,7 @@ template <int KIND> struct Lane {
         if (nan) { st |= PSH_ST_NAN; live = false; }
     }
 
-    PSH_DEV void post_policy(const RolloutArgs& a, long i, double* act) {
+    PSH_DEV void post_policy(const RolloutArgs& a, double* act) {
         bool nan = false;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
@@ -131,7 +179,7 @@ template <int KIND> struct Lane {
         if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
     }
 
-    PSH_DEV void store(const RolloutArgs& a, long i) {
+    PSH_DEV void store(const RolloutArgs& a) {
         if (a.obs) {  // final observation
             double obs[E::O];
             e.observe(obs);
@@ -154,20 +202,26 @@ template <int KIND, bool PER_ENV>
 __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
     __shared__ double lds_w[PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int F = a.num_feat;
     if (!PER_ENV) {
         for (int j = threadIdx.x; j < E::A * F; j += blockDim.x) lds_w[j] = a.pol.params[j];
         __syncthreads();
     }
-    if (i >= a.n_envs) return;
-    const double* w = PER_ENV ? a.pol.params + (long)(a.pol.policy_index ? a.pol.policy_index[i] : 0) * a.pol.num_param : lds_w;
     Lane<KIND> L;
-    L.load(a, i);
-    while (L.live) {
+    L.init();
+    const double* w = lds_w;
+    long w_env = -1;
+    for (;;) {
+        L.turnover(a);
+        if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
+        if (L.i < 0) continue;
+        if (PER_ENV && w_env != L.i) {
+            w = a.pol.params + (long)(a.pol.policy_index ? a.pol.policy_index[L.i] : 0) * a.pol.num_param;
+            w_env = L.i;
+        }
         double obs[E::O], act[E::A];
-        L.pre_policy(a, i, obs);
-        if (!L.live) break;
+        L.pre_policy(a, obs);
+        if (!L.live) continue;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) act[r] = 0.;
         int n = 0;
@@ -187,9 +241,8 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
                 n += E::O;
             }
         }
-        L.post_policy(a, i, act);
+        L.post_policy(a, act);
     }
-    L.store(a, i);
 }
 
 // ---------------------------------------------------------------------------------------- FNNPolicy rollouts
@@ -218,17 +271,18 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
     __syncthreads();
 
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < a.n_envs;
     Lane<KIND> L;
-    if (valid) L.load(a, i); else L.live = false;
+    L.init();
 
     const int n_hidden = a.pol.n_hidden;
-    while (__any(L.live)) {
+    for (;;) {
+        L.turnover(a);
+        if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         double obs[OP], act[E::A];
 #pragma unroll
         for (int r = 0; r < OP; ++r) obs[r] = 0.;
-        if (L.live) L.pre_policy(a, i, obs);
+        if (L.live) L.pre_policy(a, obs);
+        if (!__any(L.live)) continue;
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
 #pragma unroll
         for (int r = 0; r < OP; ++r) stage[r * 64 + lane] = obs[r];
@@ -296,9 +350,21 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 if (q == tile) act[r] = p;
             }
         }
-        if (L.live) L.post_policy(a, i, act);
+        if (L.live) L.post_policy(a, act);
     }
-    if (valid) L.store(a, i);
+}
+
+// QBallBalancerSim.reset: plate angles of every env by inverse kinematics, ahead of the rollout kernel, so that a lane
+// taking over a new env only reads two numbers instead of running 200 optimiser steps while its wave waits.
+__global__ __launch_bounds__(256) void k_qbb_plate(const RolloutArgs a, double* plate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs) return;
+    const long col = a.dp_index ? (long)a.dp_index[i] : i;
+    const DpCol p{a.domain_param, a.ld_dp, col};
+    const double th_x = (a.init_dim == 8) ? a.init_state[0 * a.ld_init + i] : 0.;
+    const double th_y = (a.init_dim == 8) ? a.init_state[1 * a.ld_init + i] : 0.;
+    plate[i] = qbb_ik(th_x + p[18], p[4], p[3]);
+    plate[(long)a.n_envs + i] = qbb_ik(th_y + p[19], p[4], p[3]);
 }
 
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
@@ -571,7 +637,11 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     if (!c) return PSH_ERR_ARG;
     memset(c, 0, sizeof *c);
     c->device = hip_device;
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, hip_device) != hipSuccess) { delete c; return PSH_ERR_HIP; }
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(&c->queue, 256) != hipSuccess) {
         delete c;
         return PSH_ERR_HIP;
     }
@@ -584,6 +654,8 @@ extern "C" void psh_destroy(psh_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->wfrag) (void)hipFree(c->wfrag);
+    if (c->plate) (void)hipFree(c->plate);
+    if (c->queue) (void)hipFree(c->queue);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     delete c;
@@ -621,10 +693,15 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;
-        const dim3 block(256), grid((unsigned)((d->n_envs + 255) / 256));
+        const dim3 block(256);
         if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
-        if (per_env) hipLaunchKernelGGL((k_rollout_linear<KIND, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_rollout_linear<KIND, false>), grid, block, 0, st, a);
+        if (per_env) {
+            const dim3 grid(persistent_grid(c, k_rollout_linear<KIND, true>, 256, 0, d->n_envs));
+            hipLaunchKernelGGL((k_rollout_linear<KIND, true>), grid, block, 0, st, a);
+        } else {
+            const dim3 grid(persistent_grid(c, k_rollout_linear<KIND, false>, 256, 0, d->n_envs));
+            hipLaunchKernelGGL((k_rollout_linear<KIND, false>), grid, block, 0, st, a);
+        }
         PSH_HIP(c, hipGetLastError());
         if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
         return PSH_OK;
@@ -646,11 +723,9 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
     const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = OP / 4;
     const int total = HT * K0 * 64 + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
-    if ((size_t)total > c->wfrag_doubles) {
-        if (c->wfrag) PSH_HIP(c, hipFree(c->wfrag));
-        c->wfrag = nullptr; c->wfrag_doubles = 0;
-        PSH_HIP(c, hipMalloc(&c->wfrag, (size_t)total * sizeof(double)));
-        c->wfrag_doubles = (size_t)total;
+    {
+        const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total);
+        if (rc != PSH_OK) return rc;
     }
     hipLaunchKernelGGL(k_pack_fnn, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, (int)E::O, (int)E::A,
                        HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
@@ -659,16 +734,19 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
     a.lds_doubles = total;
     constexpr int BLOCK = 512;
     const size_t lds_bytes = ((size_t)total + (BLOCK / 64) * OP * 64) * sizeof(double);
-    const dim3 block(BLOCK), grid((unsigned)((d->n_envs + BLOCK - 1) / BLOCK));
+    const dim3 block(BLOCK);
     if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
     if (HP == 16) {
         PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 16>, BLOCK, lds_bytes, d->n_envs));
         hipLaunchKernelGGL((k_rollout_fnn<KIND, 16>), grid, block, lds_bytes, st, a);
     } else if (HP == 32) {
         PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 32>, BLOCK, lds_bytes, d->n_envs));
         hipLaunchKernelGGL((k_rollout_fnn<KIND, 32>), grid, block, lds_bytes, st, a);
     } else {
         PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 64>, BLOCK, lds_bytes, d->n_envs));
         hipLaunchKernelGGL((k_rollout_fnn<KIND, 64>), grid, block, lds_bytes, st, a);
     }
     PSH_HIP(c, hipGetLastError());
@@ -704,6 +782,15 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     a.obs = d->obs; a.act = d->act; a.rew = d->rew;
     hipStream_t st = (hipStream_t)d->stream;
     c->timed = 1;
+    a.queue = c->queue;
+    PSH_HIP(c, hipMemsetAsync(c->queue, 0, 256, st));
+    if (d->env_kind == PSH_ENV_QBB && !(d->flags & PSH_F_SIMPLIFIED_DYN)) {
+        rc = ensure_doubles(c, &c->plate, &c->plate_doubles, 2 * (size_t)d->n_envs);
+        if (rc != PSH_OK) return rc;
+        hipLaunchKernelGGL(k_qbb_plate, dim3((d->n_envs + 255) / 256), dim3(256), 0, st, a, c->plate);
+        PSH_HIP(c, hipGetLastError());
+        a.plate = c->plate;
+    }
     switch (d->env_kind) {
     case PSH_ENV_QQ: return launch_rollout<PSH_ENV_QQ>(c, d, a, st);
     case PSH_ENV_QCP_SU: return launch_rollout<PSH_ENV_QCP_SU>(c, d, a, st);
