@@ -31,12 +31,13 @@ template <int KIND> struct Env;
 template <> struct Env<PSH_ENV_QQ> {
     static constexpr int S = 4, O = 6, A = 1, P = 10, I = 4, X = 0;
     double s[4];
-    double c0, c1, c2, c3, c4, km, Rm, Dr, Dp, max_volt;
+    double c0, c1, c2, c3, c4, km, Rm, rRm, Dr, Dp, max_volt;
     double sth, cth, sal, cal;  // sin/cos of s[0], s[1]: shared by observe() and the next dynamics()
 
     PSH_DEV void setup(const DpCol& p) {
         const double g = p[0], Mr = p[3], Lr = p[4], Mp = p[6], Lp = p[7];
         Rm = p[1]; km = p[2]; Dr = p[5]; Dp = p[8]; max_volt = p[9];
+        rRm = 1. / Rm;
         const double Jr = Mr * (Lr * Lr) / 12, Jp = Mp * (Lp * Lp) / 12;
         c0 = Jr + Mp * (Lr * Lr);
         c1 = 0.25 * Mp * (Lp * Lp);
@@ -60,11 +61,12 @@ template <> struct Env<PSH_ENV_QQ> {
         const double s2al = 2. * sal * cal;  // sin(2 al)
         const double a = c0 + c1 * (sal * sal), b = c2 * cal, c = c3;
         const double det = a * c - b * b;
-        const double trq = km * (u - km * thd) / Rm;
+        const double trq = psh_div_by(km * (u - km * thd), Rm, rRm);
         const double cc0 = c1 * s2al * thd * ald - c2 * sal * ald * ald;
         const double cc1 = -0.5 * c1 * s2al * thd * thd + c4 * sal;
         const double x = trq - Dr * thd - cc0, y = -Dp * ald - cc1;
-        const double thdd = (c * x - b * y) / det, aldd = (a * y - b * x) / det;
+        const double rdet = psh_rcp_refined(det);  // one reciprocal serves both quotients
+        const double thdd = psh_div_by(c * x - b * y, det, rdet), aldd = psh_div_by(a * y - b * x, det, rdet);
         // "RK4" of the reference: every stage re-evaluates the accelerations at the UN-ADVANCED state
         // (quanser_qube.py:140), so only the velocity rows of k1..k3 differ from k0.
         double kv[4][2];

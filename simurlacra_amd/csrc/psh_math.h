@@ -26,6 +26,12 @@ PSH_MATH double psh_div_moderate(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// n / d given r ~ 1/d (relative error far below 2^-26): product plus one residual correction
+PSH_MATH double psh_div_by(double n, double d, double r) {
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
 // exp(x) - 1 split as (k, q): exp(x) = 2^k * (1 + q), |q| <= 0.42.  Shared by exp, tanh and sigmoid.
 PSH_MATH double psh_exp_poly(double x, int& k) {
     const double kd = rint(x * 1.4426950408889634074);
@@ -67,6 +73,33 @@ PSH_MATH double psh_tanh(double x) {
     const double E = (k == 0) ? q : (ldexp(1.0 + q, k) - 1.0);
     const double t = psh_div_moderate(-E, 2.0 + E);   // (1 - e)/(1 + e), denominator in (1, 2]
     return copysign(t, x);
+}
+
+// tanh from a table of tanh(j/64), j = 0..1280, and the addition theorem
+//   tanh(a_j + d) = (T_j + tanh d) / (1 + T_j tanh d),   |d| <= 1/128,
+// with tanh d from its odd series (the d^9 term is below 2^-60 relative) and the quotient from a series seed of
+// 1/(1 + u), u = T_j tanh d <= 2^-7, followed by one residual correction.  About half the instructions of the
+// exponential form; the table lookup runs on the LDS pipe.  `tab` may live in LDS or in global memory.
+#define PSH_TANH_TAB_N 1281
+PSH_MATH double psh_tanh_tab(double x, const double* tab) {
+    double a = fabs(x);
+    a = (a > 20.0) ? 20.0 : a;                 // tanh(20) rounds to 1; a NaN passes through to the result
+    const double jd = rint(a * 64.0);
+    const int j = (int)jd;                      // NaN converts to 0
+    const double d = fma(jd, -0.015625, a);     // exact
+    const double T = tab[j];
+    const double z = d * d;
+    double p = fma(z, -5.396825396825397e-02, 1.3333333333333333e-01);   // -17/315, 2/15
+    p = fma(p, z, -3.3333333333333331e-01);
+    p = p * z;
+    const double td = fma(p, d, d);
+    const double u = T * td;
+    const double num = T + td;
+    const double r0 = 1.0 - u;
+    const double r1 = fma(r0, u * u, r0);       // (1 - u)(1 + u^2) = (1 - u^4)/(1 + u)
+    const double q = num * r1;
+    const double res = fma(-u, q, num - q);     // num - (1 + u) q; num - q is exact
+    return copysign(fma(res, r1, q), x);
 }
 
 PSH_MATH double psh_sigmoid(double x) {
@@ -114,6 +147,7 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
 // C fmod (sign of x, exact) for quotients below 2^52; library path otherwise
 PSH_MATH double psh_fmod(double x, double m) {
     const double am = fabs(m);
+    if (fabs(x) < am) return x;   // already reduced: the common case in the step loop
     const double qd = x / am;
     if (!(fabs(qd) < 4503599627370496.0) || am == 0.0) return fmod(x, m);
     const double q = trunc(qd);

@@ -10,6 +10,7 @@
 //   k_qbb_ik, k_segment_mean, k_pack_fnn
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -26,6 +27,7 @@ struct psh_ctx {
     double* plate;       // QBB plate angles of the IK prologue [2, N], grown on demand
     size_t plate_doubles;
     unsigned int* queue; // work-queue counter of the rollout kernels
+    double* tanh_tab;    // tanh(j/64), j = 0..1280 (psh_tanh_tab)
     int num_cus;
     hipEvent_t ev0, ev1;
     int timed;
@@ -80,7 +82,18 @@ struct RolloutArgs {
     double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
     unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
     const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
+    const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
 };
+
+// The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
+// pulled into scalar registers for the whole loop and spill.
+constexpr int TASK_DOUBLES = (sizeof(psh_task) + 7) / 8;
+constexpr int TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
+
+__device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
+    const double* src = reinterpret_cast<const double*>(&a.task);
+    for (int j = threadIdx.x; j < TASK_DOUBLES; j += blockDim.x) dst[j] = src[j];
+}
 
 // ------------------------------------------------------------------------------------------------ math helpers
 PSH_DEV double nl_apply(int nl, double v) {
@@ -123,19 +136,19 @@ template <int KIND> struct Lane {
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
     // an env has no influence on its results.
-    PSH_DEV void turnover(const RolloutArgs& a) {
+    PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task) {
         if (i >= 0 && !live) { store(a); i = -1; }
         if (i < 0 && !exhausted) {
             const unsigned int nxt = atomicAdd(a.queue, 1u);
-            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a); } else { exhausted = true; }
+            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a, task); } else { exhausted = true; }
         }
     }
 
-    PSH_DEV void load(const RolloutArgs& a) {
+    PSH_DEV void load(const RolloutArgs& a, const psh_task& task) {
         const long col = a.dp_index ? (long)a.dp_index[i] : i;
         const DpCol p{a.domain_param, a.ld_dp, col};
         e.setup(p);
-        c_max = task_c_max<KIND>(e, a.task);
+        c_max = task_c_max<KIND>(e, task);
         double init[E::S];
         for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * a.ld_init + i] : 0.;
         if constexpr (KIND == PSH_ENV_QBB) {
@@ -161,12 +174,12 @@ template <int KIND> struct Lane {
         if (nan) { st |= PSH_ST_NAN; live = false; }
     }
 
-    PSH_DEV void post_policy(const RolloutArgs& a, double* act) {
+    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, double* act) {
         bool nan = false;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
         if (nan) { st |= PSH_ST_NAN; live = false; return; }
-        const double rew = env_step<KIND>(e, a.task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false,
+        const double rew = env_step<KIND>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false,
                                           (a.flags & PSH_F_SIMPLIFIED_DYN) != 0, done, st);
         if (a.act) {
 #pragma unroll
@@ -201,18 +214,23 @@ template <int KIND> struct Lane {
 template <int KIND, bool PER_ENV>
 __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
-    __shared__ double lds_w[PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS];
+    constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS;
+    __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
+    double* const lds_w = lds_lin;
+    const psh_task& task = *reinterpret_cast<const psh_task*>(lds_lin + W_DOUBLES);
     const int F = a.num_feat;
     if (!PER_ENV) {
         for (int j = threadIdx.x; j < E::A * F; j += blockDim.x) lds_w[j] = a.pol.params[j];
-        __syncthreads();
     }
+    stage_task(a, lds_lin + W_DOUBLES);
+    __syncthreads();
     Lane<KIND> L;
     L.init();
     const double* w = lds_w;
     long w_env = -1;
     for (;;) {
-        L.turnover(a);
+        asm volatile("" ::: "memory");  // keep the LDS constants out of registers across iterations
+        L.turnover(a, task);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         if (L.i < 0) continue;
         if (PER_ENV && w_env != L.i) {
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
                 n += E::O;
             }
         }
-        L.post_policy(a, act);
+        L.post_policy(a, task, act);
     }
 }
 
@@ -254,9 +272,27 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
 // cross-lane movement.  A wave owns 64 envs (lane = env for the dynamics) and runs the policy as 4 tiles of 16
 // envs; only the observations (through an LDS staging row per wave) and the action (two xor-shuffles) cross lanes.
 //
+// On gfx950 the fp64 MFMA and the fp64 vector instructions share one pipe (64 and 4 cycles per instruction, no
+// overlap, also not between waves), so every vector instruction next to the MFMAs costs throughput: the activation
+// function is the table-based psh_tanh_tab and the loop keeps its constants in LDS rather than in registers.
+//
 // Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = OP/4 with OP = observation rows padded to 4:
 //   [HT*K0 frags of 64][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then [Wout: A*HP][bout: 2]
+// Dynamic LDS: [weight image][8 staging areas of OP*64][tanh table][task]
 typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int N> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
+    if (nl == PSH_NL_TANH) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
+    } else if (nl == PSH_NL_SIGMOID) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) y[m] = psh_sigmoid(y[m]);
+    } else if (nl == PSH_NL_RELU) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) y[m] = y[m] > 0. ? y[m] : 0.;
+    }
+}
 
 template <int KIND, int HP>
 __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
@@ -267,8 +303,13 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
     double* const stage = lds + a.lds_doubles + wave * (OP * 64);
+    double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
+    double* const task_lds = tanh_tab + TANH_TAB_PAD;
+    const psh_task& task = *reinterpret_cast<const psh_task*>(task_lds);
 
     for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    for (int j = threadIdx.x; j < PSH_TANH_TAB_N; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
+    stage_task(a, task_lds);
     __syncthreads();
 
     Lane<KIND> L;
@@ -276,7 +317,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 
     const int n_hidden = a.pol.n_hidden;
     for (;;) {
-        L.turnover(a);
+        L.turnover(a, task);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         double obs[OP], act[E::A];
 #pragma unroll
@@ -291,7 +332,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         for (int tile = 0; tile < 4; ++tile) {
-            double x[KS], y[KS];
+            double y[KS];
             // layer 0
             {
                 double xin[K0];
@@ -310,13 +351,12 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                const int nl = a.pol.hidden_nonlin[0];
-#pragma unroll
-                for (int m = 0; m < KS; ++m) y[m] = nl_apply(nl, y[m]);
+                nl_apply_all<KS>(a.pol.hidden_nonlin[0], y, tanh_tab);
             }
             // further hidden layers
             int off = HT * K0 * 64 + HP;
             for (int l = 1; l < n_hidden; ++l) {
+                double x[KS];
 #pragma unroll
                 for (int m = 0; m < KS; ++m) x[m] = y[m];
                 const double* wl = w_lds + off;
@@ -332,9 +372,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                const int nl = a.pol.hidden_nonlin[l];
-#pragma unroll
-                for (int m = 0; m < KS; ++m) y[m] = nl_apply(nl, y[m]);
+                nl_apply_all<KS>(a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
@@ -346,11 +384,12 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 for (int m = 0; m < KS; ++m) p += wo[r * HP + (m >> 2) * 16 + (m & 3) * 4 + q] * y[m];
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
-                p = nl_apply(a.pol.out_nonlin, p + wo[E::A * HP + r]);
+                p += wo[E::A * HP + r];
+                nl_apply_all<1>(a.pol.out_nonlin, &p, tanh_tab);
                 if (q == tile) act[r] = p;
             }
         }
-        if (L.live) L.post_policy(a, act);
+        if (L.live) L.post_policy(a, task, act);
     }
 }
 
@@ -596,7 +635,7 @@ __global__ __launch_bounds__(256) void k_segment_mean(int n_groups, int group_si
 }
 
 // element-wise evaluation of the device math functions (accuracy tests)
-__global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* x, const double* m, double* y) {
+__global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* x, const double* m, double* y, const double* tanh_tab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s, c;
@@ -606,6 +645,7 @@ __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* 
     case 2: y[i] = psh_sigmoid(x[i]); break;
     case 3: psh_sincos(x[i], &s, &c); y[i] = s; break;
     case 4: psh_sincos(x[i], &s, &c); y[i] = c; break;
+    case 6: y[i] = psh_tanh_tab(x[i], tanh_tab); break;
     default: y[i] = psh_fmod(x[i], m[i]);
     }
 }
@@ -640,8 +680,11 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) != hipSuccess) { delete c; return PSH_ERR_HIP; }
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    double tab[PSH_TANH_TAB_N];
+    for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[j] = (double)tanhl((long double)j / 64.0L);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc(&c->queue, 256) != hipSuccess) {
+        hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, sizeof tab) != hipSuccess ||
+        hipMemcpy(c->tanh_tab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
         delete c;
         return PSH_ERR_HIP;
     }
@@ -656,6 +699,7 @@ extern "C" void psh_destroy(psh_ctx* c) {
     if (c->wfrag) (void)hipFree(c->wfrag);
     if (c->plate) (void)hipFree(c->plate);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->tanh_tab) (void)hipFree(c->tanh_tab);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     delete c;
@@ -731,9 +775,10 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
                        HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
+    a.tanh_tab = c->tanh_tab;
     a.lds_doubles = total;
     constexpr int BLOCK = 512;
-    const size_t lds_bytes = ((size_t)total + (BLOCK / 64) * OP * 64) * sizeof(double);
+    const size_t lds_bytes = ((size_t)total + (BLOCK / 64) * OP * 64 + TANH_TAB_PAD + TASK_DOUBLES) * sizeof(double);
     const dim3 block(BLOCK);
     if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
     if (HP == 16) {
@@ -930,7 +975,7 @@ extern "C" int psh_eval_math(psh_ctx* c, int32_t fn, int32_t n, const double* x,
     if (!c || fn < 0 || fn > 5 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
     if (n == 0) return PSH_OK;
     PSH_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_eval_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)fn, (int)n, x, m, y);
+    hipLaunchKernelGGL(k_eval_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)fn, (int)n, x, m, y, (const double*)c->tanh_tab);
     PSH_HIP(c, hipGetLastError());
     return PSH_OK;
 }
