@@ -305,7 +305,8 @@ int psh_segment_mean(psh_ctx* ctx, int32_t n_groups, int32_t group_size, const d
 
 /* Diagnostic, no counterpart in the reference: evaluates one of the device's fp64 elementary functions
  * (the ones the step loop uses in place of NumPy's np.exp / np.tanh / np.sin / np.cos / np.fmod) element-wise, so that
- * their accuracy can be tested directly.  fn: 0 exp, 1 tanh, 2 sigmoid, 3 sin, 4 cos, 5 fmod(x[i], m[i]). */
+ * their accuracy can be tested directly.  fn: 0 exp, 1 tanh (exponential form), 2 sigmoid, 3 sin, 4 cos,
+ * 5 fmod(x[i], m[i]), 6 / 7 tanh from the fine / coarse lookup table (the forms the FNNPolicy kernels use). */
 int psh_eval_math(psh_ctx* ctx, int32_t fn, int32_t n, const double* x /*[dev][n]*/, const double* m /*[dev][n] or NULL*/,
                   double* y /*[dev][n]*/, void* stream);
 

@@ -75,15 +75,47 @@ PSH_MATH double psh_tanh(double x) {
     return copysign(t, x);
 }
 
-// tanh from a table of tanh(j/64), j = 0..1280, and the addition theorem
-//   tanh(a_j + d) = (T_j + tanh d) / (1 + T_j tanh d),   |d| <= 1/128,
-// with tanh d from its odd series (the d^9 term is below 2^-60 relative) and the quotient from a series seed of
-// 1/(1 + u), u = T_j tanh d <= 2^-7, followed by one residual correction.  About half the instructions of the
-// exponential form; the table lookup runs on the LDS pipe.  `tab` may live in LDS or in global memory.
+// tanh from a table and the addition theorem, in two variants that differ in table spacing.  Both split
+// |x| = a_j + d with a_j the nearest table node, take T_j = tanh(a_j) from the table (`tab` may live in LDS or in
+// global memory; the lookup runs on the LDS pipe, not on the vector ALU) and tanh d from its odd series.
+//
+// Fine table, tanh(j/256), j = 0..5120, |d| <= 2^-9 (18 vector instructions, about 1.2 ulp, 2 ulp next to 0):
+//   tanh(a_j + d) = T + (1 - T^2) td / (1 + T td),   1/(1 + u) = (1 - u)(1 + u^2 + u^4) + O(u^6),  u = T td <= 2^-9.
+// Adding 1.5 * 2^44 rounds |x| to a multiple of 1/256 and leaves that multiple in the low word of the sum.
+// The work is split into an index step and a finish step so that a caller can issue all its table loads first.
+#define PSH_TANH8_N 5121
+PSH_MATH unsigned psh_tanh8_index(double x, double* d) {
+    double a = fabs(x);
+    a = (a > 20.0) ? 20.0 : a;                 // tanh(20) rounds to 1; a NaN passes through d to the result
+    const double jm = a + 26388279066624.0;    // 1.5 * 2^44
+    *d = a - (jm - 26388279066624.0);
+    const unsigned j = (unsigned)__double2loint(jm);
+    return j > 5120u ? 5120u : j;              // only a NaN with payload bits can get here out of range
+}
+PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
+    const double z = d * d;
+    const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;   // 2/15, -1/3; d^7 is below 2^-58
+    const double td = fma(p, d, d);
+    const double u = T * td;
+    const double S = fma(-T, T, 1.0);
+    const double r0 = 1.0 - u;
+    const double e = u * u;
+    const double w = fma(r0, fma(e, e, e), r0);
+    return copysign(fma(S, td * w, T), x);
+}
+PSH_MATH double psh_tanh8(double x, const double* tab) {
+    double d;
+    const unsigned j = psh_tanh8_index(x, &d);
+    return psh_tanh8_finish(x, d, tab[j]);
+}
+
+// Coarse table, tanh(j/64), j = 0..1280, |d| <= 2^-7 (23 vector instructions, 2 ulp): for kernels whose LDS has no
+// room for the fine table.  tanh(a_j + d) = (T + td)/(1 + T td) with a series seed of the reciprocal and one
+// residual correction of the quotient.
 #define PSH_TANH_TAB_N 1281
 PSH_MATH double psh_tanh_tab(double x, const double* tab) {
     double a = fabs(x);
-    a = (a > 20.0) ? 20.0 : a;                 // tanh(20) rounds to 1; a NaN passes through to the result
+    a = (a > 20.0) ? 20.0 : a;
     const double jd = rint(a * 64.0);
     const int j = (int)jd;                      // NaN converts to 0
     const double d = fma(jd, -0.015625, a);     // exact

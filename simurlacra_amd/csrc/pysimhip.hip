@@ -27,8 +27,9 @@ struct psh_ctx {
     double* plate;       // QBB plate angles of the IK prologue [2, N], grown on demand
     size_t plate_doubles;
     unsigned int* queue; // work-queue counter of the rollout kernels
-    double* tanh_tab;    // tanh(j/64), j = 0..1280 (psh_tanh_tab)
+    double* tanh_tab;    // [tanh(j/256), j = 0..5120 (psh_tanh8)][tanh(j/64), j = 0..1280 (psh_tanh_tab)]
     int num_cus;
+    size_t lds_per_block;
     hipEvent_t ev0, ev1;
     int timed;
 };
@@ -83,12 +84,13 @@ struct RolloutArgs {
     unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
     const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
     const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
+    int tanh_n;              // its length (fine or coarse table)
 };
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
 // pulled into scalar registers for the whole loop and spill.
 constexpr int TASK_DOUBLES = (sizeof(psh_task) + 7) / 8;
-constexpr int TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
+constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
 
 __device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
     const double* src = reinterpret_cast<const double*>(&a.task);
@@ -278,13 +280,27 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
 //
 // Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = OP/4 with OP = observation rows padded to 4:
 //   [HT*K0 frags of 64][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then [Wout: A*HP][bout: 2]
-// Dynamic LDS: [weight image][8 staging areas of OP*64][tanh table][task]
+// Dynamic LDS: [weight image][8 staging areas of OP*64][tanh table][task].  FINE selects the fine tanh table (40 KB);
+// the widest, deepest networks leave no room for it and run with the coarse one.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int N> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
+template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
+        if (FINE) {
+            // all table loads first, then the arithmetic: the LDS latency is paid once per layer, not per element
+            constexpr int CH = N < 8 ? N : 8;  // chunked: d and T of a whole layer would not fit the register file
 #pragma unroll
-        for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
+            for (int m0 = 0; m0 < N; m0 += CH) {
+                double d[CH], T[CH];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) T[m] = tanh_tab[psh_tanh8_index(y[m0 + m], &d[m])];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
+        }
     } else if (nl == PSH_NL_SIGMOID) {
 #pragma unroll
         for (int m = 0; m < N; ++m) y[m] = psh_sigmoid(y[m]);
@@ -294,7 +310,7 @@ template <int N> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh
     }
 }
 
-template <int KIND, int HP>
+template <int KIND, int HP, bool FINE>
 __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
@@ -304,11 +320,11 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     const int q = lane >> 4, c = lane & 15;
     double* const stage = lds + a.lds_doubles + wave * (OP * 64);
     double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
-    double* const task_lds = tanh_tab + TANH_TAB_PAD;
+    double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_lds);
 
     for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
-    for (int j = threadIdx.x; j < PSH_TANH_TAB_N; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
+    for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
     stage_task(a, task_lds);
     __syncthreads();
 
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                nl_apply_all<KS>(a.pol.hidden_nonlin[0], y, tanh_tab);
+                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[0], y, tanh_tab);
             }
             // further hidden layers
             int off = HT * K0 * 64 + HP;
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                nl_apply_all<KS>(a.pol.hidden_nonlin[l], y, tanh_tab);
+                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
                 p += wo[E::A * HP + r];
-                nl_apply_all<1>(a.pol.out_nonlin, &p, tanh_tab);
+                nl_apply_all<1, FINE>(a.pol.out_nonlin, &p, tanh_tab);
                 if (q == tile) act[r] = p;
             }
         }
@@ -645,7 +661,8 @@ __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* 
     case 2: y[i] = psh_sigmoid(x[i]); break;
     case 3: psh_sincos(x[i], &s, &c); y[i] = s; break;
     case 4: psh_sincos(x[i], &s, &c); y[i] = c; break;
-    case 6: y[i] = psh_tanh_tab(x[i], tanh_tab); break;
+    case 6: y[i] = psh_tanh8(x[i], tanh_tab); break;
+    case 7: y[i] = psh_tanh_tab(x[i], tanh_tab + PSH_TANH8_N); break;
     default: y[i] = psh_fmod(x[i], m[i]);
     }
 }
@@ -680,8 +697,12 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) != hipSuccess) { delete c; return PSH_ERR_HIP; }
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-    double tab[PSH_TANH_TAB_N];
-    for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[j] = (double)tanhl((long double)j / 64.0L);
+    // the LDS one workgroup may claim through hipFuncAttributeMaxDynamicSharedMemorySize: all of a CU's (160 KB on gfx950)
+    c->lds_per_block = prop.maxSharedMemoryPerMultiProcessor > prop.sharedMemPerBlock ? prop.maxSharedMemoryPerMultiProcessor
+                                                                                      : prop.sharedMemPerBlock;
+    static double tab[PSH_TANH8_N + PSH_TANH_TAB_N];
+    for (int j = 0; j < PSH_TANH8_N; ++j) tab[j] = (double)tanhl((long double)j / 256.0L);
+    for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, sizeof tab) != hipSuccess ||
         hipMemcpy(c->tanh_tab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
@@ -775,25 +796,28 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
                        HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
-    a.tanh_tab = c->tanh_tab;
     a.lds_doubles = total;
     constexpr int BLOCK = 512;
-    const size_t lds_bytes = ((size_t)total + (BLOCK / 64) * OP * 64 + TANH_TAB_PAD + TASK_DOUBLES) * sizeof(double);
+    const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;
+    const bool fine = (base_doubles + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
+    a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
+    a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
+    const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
+    if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
     const dim3 block(BLOCK);
     if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
-    if (HP == 16) {
-        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 16>, BLOCK, lds_bytes, d->n_envs));
-        hipLaunchKernelGGL((k_rollout_fnn<KIND, 16>), grid, block, lds_bytes, st, a);
-    } else if (HP == 32) {
-        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 32>, BLOCK, lds_bytes, d->n_envs));
-        hipLaunchKernelGGL((k_rollout_fnn<KIND, 32>), grid, block, lds_bytes, st, a);
-    } else {
-        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, 64>, BLOCK, lds_bytes, d->n_envs));
-        hipLaunchKernelGGL((k_rollout_fnn<KIND, 64>), grid, block, lds_bytes, st, a);
-    }
+#define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                   \
+    do {                                                                                                             \
+        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, HP_, FINE_>,                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                 \
+        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, HP_, FINE_>, BLOCK, lds_bytes, d->n_envs));            \
+        hipLaunchKernelGGL((k_rollout_fnn<KIND, HP_, FINE_>), grid, block, lds_bytes, st, a);                         \
+    } while (0)
+    if (HP == 16) PSH_LAUNCH_FNN(16, true);
+    else if (HP == 32) PSH_LAUNCH_FNN(32, true);
+    else if (fine) PSH_LAUNCH_FNN(64, true);
+    else PSH_LAUNCH_FNN(64, false);
+#undef PSH_LAUNCH_FNN
     PSH_HIP(c, hipGetLastError());
     if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
     return PSH_OK;
@@ -972,7 +996,7 @@ extern "C" int psh_segment_mean(psh_ctx* c, int32_t n_groups, int32_t group_size
 }
 
 extern "C" int psh_eval_math(psh_ctx* c, int32_t fn, int32_t n, const double* x, const double* m, double* y, void* stream) {
-    if (!c || fn < 0 || fn > 5 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
+    if (!c || fn < 0 || fn > 7 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
     if (n == 0) return PSH_OK;
     PSH_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_eval_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)fn, (int)n, x, m, y, (const double*)c->tanh_tab);

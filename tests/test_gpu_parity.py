@@ -52,6 +52,30 @@ def test_rollout_fnn_policy(eng, orc, kind, hidden):
     _compare_rollouts(eng, orc, case, T=50)
 
 
+@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB])
+def test_rollout_deepest_widest_fnn(eng, orc, kind):
+    """ 4 hidden layers of 64: the weight image leaves no LDS for the fine tanh table, the kernel variant with the
+    coarse table runs. """
+    # small weights and a short horizon: with a high-gain random policy the closed loop is chaotic and a one-ulp
+    # difference (the oracle's own, under a perturbed initial state) grows past the tolerance within 20 steps
+    case = cases.make_case(kind, 150, seed=31 + kind, policy='fnn', hidden=(64, 64, 64, 64), scale=0.15)
+    _compare_rollouts(eng, orc, case, T=25)
+
+
+@pytest.mark.parametrize('hidden', [(64, 64), (64, 64, 64, 64)])
+def test_fnn_nan_parameter_is_flagged(eng, orc, hidden):
+    """ A NaN weight must reach the action through the activation function (both tanh table variants). """
+    kind = abi.ENV_QQ
+    case = cases.make_case(kind, 70, seed=77, policy='fnn', hidden=hidden)
+    params = case['params'].copy()
+    params[5] = np.nan
+    ref = orc.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], params, case['init'], case['dp'])
+    out = eng.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], params, case['init'], case['dp'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)
+
+
 @pytest.mark.parametrize('kind', cases.KINDS)
 def test_reset_step(eng, orc, kind):
     import torch
@@ -201,8 +225,11 @@ def test_device_math_accuracy(eng):
     x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-2, 2, 20000), [0., -0., 1e-300, -745.2, 709.7]])
     assert _ulp_err(eng.eval_math('exp', x).cpu().numpy(), np.exp(x)).max() <= 2
     x = np.concatenate([rng.uniform(-25, 25, 20000), rng.uniform(-1, 1, 20000), 10.**rng.uniform(-12, 0, 5000), [0., 40., -40.]])
-    got, ref = eng.eval_math('tanh', x).cpu().numpy(), np.tanh(x)
-    assert _ulp_err(got[ref != 0], ref[ref != 0]).max() <= 4 and np.all(got[ref == 0] == 0)
+    x = np.concatenate([x, np.arange(0, 5121)/256., np.arange(0, 5121)/256. + 1/512., [20., 20.000001, 1e300, -1e300]])
+    for fn in ('tanh', 'tanh_table_fine', 'tanh_table_coarse'):  # exponential form and the two table forms of the FNN kernel
+        got, ref = eng.eval_math(fn, x).cpu().numpy(), np.tanh(x)
+        assert _ulp_err(got[ref != 0], ref[ref != 0]).max() <= 4 and np.all(got[ref == 0] == 0), fn
+        assert np.all(np.signbit(got) == np.signbit(x)), fn
     x = np.concatenate([rng.uniform(-40, 40, 20000), [0., 800., -800.]])
     got, ref = eng.eval_math('sigmoid', x).cpu().numpy(), 1/(1 + np.exp(-x))
     assert np.abs(got - ref).max() <= 3e-16 and _ulp_err(got[np.abs(x) < 30], ref[np.abs(x) < 30]).max() <= 4
@@ -216,5 +243,7 @@ def test_device_math_accuracy(eng):
     np.testing.assert_array_equal(got, ref)
     np.testing.assert_array_equal(np.signbit(got), np.signbit(ref))
     nan_in = np.array([np.nan, np.inf, -np.inf])
-    assert np.all(np.isnan(eng.eval_math('tanh', nan_in).cpu().numpy()) == [True, False, False])
+    for fn in ('tanh', 'tanh_table_fine', 'tanh_table_coarse'):
+        got = eng.eval_math(fn, nan_in).cpu().numpy()
+        assert np.isnan(got[0]) and got[1] == 1. and got[2] == -1., fn
     assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
