@@ -29,6 +29,9 @@ from simurlacra_amd.specs import PolicySpec  # noqa: E402
 
 FLOP_PER_STEP = 9352          # algorithmic fp64 flop per env-step, QQube + FNN 64x64 (transcendentals counted as 1)
 FP64_PEAK_TFLOPS = 78.6       # MI355X dense FP64 (matrix = vector rate: half the 157.3 TF FP32 peak)
+# HBM bytes per launch of the rollout kernel cannot be measured from inside this script: they come from the rocprofv3
+# counter passes over this same command (tools/profile_bench.sh), whose summary is committed next to the kernel trace.
+TRAFFIC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_bench_summary.json')
 DT, T = 1/500., 600
 
 
@@ -147,6 +150,11 @@ def main():
     steps_k = int(steps_k.item())
     achieved = FLOP_PER_STEP*steps_k/(k_ms*1e-3)/1e12
 
+    traffic = None
+    if os.path.exists(TRAFFIC_SUMMARY) and (n_sets, R) == (8, 262144):  # the summary holds for the default workload only
+        with open(TRAFFIC_SUMMARY) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')
+
     res = None
     if rank == 0:
         res = {
@@ -159,7 +167,7 @@ def main():
                        'domain_param_sets_per_gpu': n_sets, 'rollouts_per_set': R, 'envs_per_gpu': N,
                        'env_steps_counted': 'executed before done', 'parallelism': f'env-sharded x{world}'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': 'k_rollout_fnn<QQ,64>', 'kernel_ms': k_ms, 'env_steps_per_launch': steps_k,
                          'flop_per_env_step': FLOP_PER_STEP},
         }
