@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 100
+#define PSH_VERSION 101
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -41,6 +41,7 @@ extern "C" {
 #define PSH_MAX_FEATS 8   /* feature functions in a LinearPolicy's FeatureStack    */
 #define PSH_MAX_DISTR 32  /* distributions in one randomizer                       */
 #define PSH_MAX_DELAY 32  /* longest action delay (steps) of the fused ActDelay    */
+#define PSH_MAX_WRAP 6    /* fused environment wrappers around one simulation      */
 
 typedef enum psh_status {
     PSH_OK = 0,
@@ -148,6 +149,48 @@ typedef struct psh_policy {
 #define PSH_ST_FAILED 2   /* state left the (inclusive) state-space box: task.has_failed        */
 #define PSH_ST_TIMEOUT 4  /* curr_step reached max_steps                                        */
 
+/* Environment wrappers fused into the rollout (Pyrado/pyrado/environment_wrappers/): what EnvWrapperAct.step
+ * and EnvWrapperObs.reset/step (base.py:145-231) do around the simulation each step.  `ops` lists the wrappers
+ * OUTERMOST FIRST (domain-randomization wrappers are not part of it); each kind may appear once.  The action of the
+ * policy passes through the action wrappers in that order, the observation of the simulation through the
+ * observation wrappers in the reverse order, as the nesting of the Python objects implies.
+ *  ACT_NORM     ActNormWrapper._process_act           action_normalization.py:10-22
+ *               a = lo + (a + 1) (hi - lo) / 2 with the simulation's own (parameter-dependent) action bounds
+ *  ACT_DELAY    ActDelayWrapper.reset/_process_act    action_delay.py:55-81
+ *               FIFO pre-filled with `delay` zero actions; delay = `act_delay`, or per env the integer in row
+ *               `act_delay_row` of the domain-parameter table (the randomized 'act_delay' parameter, :46-53).
+ *               The queue holds the caller's array OBJECTS: with no array-creating wrapper (ACT_NORM, ACT_NOISE)
+ *               between it and QBallBalancerSim, the simulation's in-place dead-zone write lands in the action
+ *               recorded `delay` steps earlier.
+ *  ACT_NOISE    GaussianActNoiseWrapper._process_act  action_noise.py:42-47     a + randn * std + mean
+ *  OBS_NOISE    GaussianObsNoiseWrapper._process_obs  observation_noise.py:34-39  o + randn * std + mean
+ *  OBS_NORM     ObsNormWrapper._process_obs           observation_normalization.py:73-86
+ *               (o - lo) / (hi - lo) * 2 - 1; obs_lo/obs_hi hold the bounds after the explicit overrides, NaN
+ *               entries mean "the simulation's own bound for this env" (it may depend on its parameters)
+ *  OBS_PARTIAL  ObsPartialWrapper._process_obs        observation_partial.py:43-44   o[keep_mask]
+ * Vectors are indexed by the SIMULATION's observation / action index whatever the position of OBS_PARTIAL; the
+ * policy sees, and `obs` records, the kept entries in order (their count is the policy's input dimension).
+ * The reference draws the noise from NumPy's global generator; here it is Philox4x32-10 keyed by
+ * (noise_seed, global env index = env_offset + i, step), so only the distribution can agree with it. */
+typedef enum psh_wrap_op {
+    PSH_WRAP_ACT_NORM = 1, PSH_WRAP_ACT_DELAY = 2, PSH_WRAP_ACT_NOISE = 3,
+    PSH_WRAP_OBS_NOISE = 4, PSH_WRAP_OBS_NORM = 5, PSH_WRAP_OBS_PARTIAL = 6
+} psh_wrap_op;
+
+typedef struct psh_wrappers {
+    int32_t n_ops;                /* 0: bare simulation */
+    int32_t ops[PSH_MAX_WRAP];    /* psh_wrap_op, outermost first */
+    int32_t act_delay;            /* ACT_DELAY: delay in steps (0..PSH_MAX_DELAY) when act_delay_row < 0 */
+    int32_t act_delay_row;        /* ACT_DELAY: row of domain_param with the per-env delay, or -1 */
+    int32_t obs_keep_mask;        /* OBS_PARTIAL: bit r set = observation r of the simulation is kept */
+    int32_t pad_[2];
+    uint64_t noise_seed;
+    uint64_t env_offset;
+    double act_noise_mean[PSH_MAX_ACT], act_noise_std[PSH_MAX_ACT];
+    double obs_noise_mean[PSH_MAX_OBS], obs_noise_std[PSH_MAX_OBS];
+    double obs_lo[PSH_MAX_OBS], obs_hi[PSH_MAX_OBS];
+} psh_wrappers;
+
 typedef struct psh_ctx psh_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -188,17 +231,18 @@ typedef struct psh_rollout_desc {
     const double* domain_param; /* [dev] */
     const int32_t* dp_index;    /* [dev] or NULL */
     int32_t ld_dp;
-    int32_t act_delay_row;      /* -1: no ActDelayWrapper; else extra row of domain_param holding the per-env
-                                   integer delay (Pyrado/pyrado/environment_wrappers/action_delay.py:46-81) */
+    int32_t pad_;
     psh_task task;
     psh_policy policy;
+    psh_wrappers wrap;          /* [host] fused environment wrappers; all-zero = none */
     /* outputs, all [dev]; ret/length/status are mandatory, the rest may be NULL */
     double* ret;          /* [N]   undiscounted return = sum of rewards (step_sequence.py:626-635) */
     int32_t* length;      /* [N]   number of executed steps (rollout length) */
     int32_t* status;      /* [N]   PSH_ST_* bits */
     double* final_state;  /* [S, N] ld = N, state after the last executed step */
-    double* obs;          /* [T+1, O, N] observations incl. the final one; rows past length+1 untouched */
-    double* act;          /* [T, A, N]   recorded actions (raw policy output; QBB: dead-zoned, see header note) */
+    double* obs;          /* [T+1, O', N] observations incl. the final one (O' = O, or the kept entries of
+                             OBS_PARTIAL); rows past length+1 untouched */
+    double* act;          /* [T, A, N]   recorded actions (raw policy output; QBB: dead-zoned, see ACT_DELAY) */
     double* rew;          /* [T, N]      step rewards (final reward folded into the last step) */
     void* stream;
 } psh_rollout_desc;

@@ -60,9 +60,10 @@ def _f64(a):
 
 
 def rollout(env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *, flags=abi.F_STOP_ON_DONE,
-            dp_index=None, policy_index=None, record=False, act_delay_row=-1, n_threads=0):
+            dp_index=None, policy_index=None, record=False, wrap=None, n_threads=0):
     """ N rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]. """
     S, O, A, P, _ = abi.ENV_DIMS[env_kind]
+    O_rec = O if wrap is None else wrap.obs_dim(O)
     init_state, domain_param, params = _f64(init_state), _f64(domain_param), np.atleast_2d(_f64(params))
     N = init_state.shape[1]
     T = int(max_steps)
@@ -71,11 +72,13 @@ def rollout(env_kind, dt, max_steps, task_c, policy_spec, params, init_state, do
     out = dict(ret=np.zeros(N), length=np.zeros(N, dtype=np.int32), status=np.zeros(N, dtype=np.int32),
                final_state=np.zeros((S, N)))
     if record:
-        out.update(obs=np.full((T + 1, O, N), np.nan), act=np.full((T, A, N), np.nan), rew=np.full((T, N), np.nan))
+        out.update(obs=np.full((T + 1, O_rec, N), np.nan), act=np.full((T, A, N), np.nan), rew=np.full((T, N), np.nan))
     d = abi.PshRolloutDesc()
     d.env_kind, d.n_envs, d.max_steps, d.flags, d.dt = env_kind, N, T, flags, dt
     d.init_state, d.init_dim, d.ld_init = _ptr(init_state), init_state.shape[0], N
-    d.domain_param, d.dp_index, d.ld_dp, d.act_delay_row = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1], act_delay_row
+    d.domain_param, d.dp_index, d.ld_dp = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1]
+    if wrap is not None:
+        d.wrap = wrap.to_c(O, A)
     d.task = task_c
     d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index))
     d.ret, d.length, d.status, d.final_state = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status']), _ptr(out['final_state'])

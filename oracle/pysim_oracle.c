@@ -507,9 +507,88 @@ int orc_policy_forward(const psh_policy* pol, int O, int A, const double* obs, d
     return 0;
 }
 
+/* ---- fused environment wrappers (the modules of environment_wrappers), see psh_wrappers in the header ---- */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+static double u01(uint32_t hi, uint32_t lo);
+
+/* n standard normals for (seed, env, step t, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p */
+static void step_normals(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, int n, double* out) {
+    for (int p = 0; 2 * p < n; ++p) {
+        uint32_t ctr[4] = {(uint32_t)env, (uint32_t)(env >> 32), t, stream + 16u * (uint32_t)p};
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        uint32_t o[4];
+        philox4x32_10(ctr, key, o);
+        double ua = u01(o[0], o[1]), ub = u01(o[2], o[3]);
+        double r = sqrt(-2.0 * log(1.0 - ua));
+        out[2 * p] = r * cos(2.0 * ORC_PI * ub);
+        if (2 * p + 1 < n) out[2 * p + 1] = r * sin(2.0 * ORC_PI * ub);
+    }
+}
+
+/* observation-space bounds of the simulation: pysim/quanser_qube.py:25-33, quanser_cartpole.py:45-50,
+ * quanser_ball_balancer.py:73, ball_on_beam.py:32, one_mass_oscillator.py:39 */
+static void sim_obs_bounds(const orc_env* e, double* lo, double* hi) {
+    switch (e->kind) {
+    case PSH_ENV_QQ: {
+        const double m[6] = {1., 1., 1., 1., INFINITY, INFINITY};
+        for (int r = 0; r < 6; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
+        break;
+    }
+    case PSH_ENV_QCP_SU:
+    case PSH_ENV_QCP_ST: {
+        const double m[5] = {e->dp[2] / 2., 1., 1., INFINITY, INFINITY};
+        for (int r = 0; r < 5; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
+        break;
+    }
+    default:
+        for (int r = 0; r < e->O; ++r) { lo[r] = e->s_lo[r]; hi[r] = e->s_hi[r]; }
+    }
+}
+
+/* EnvWrapperObs.reset/step: the simulation's observation through the observation wrappers, innermost first;
+ * returns the number of entries the policy sees */
+static int wrap_obs(const psh_wrappers* w, const orc_env* e, uint64_t env, uint32_t t, const double* sim_obs, double* out) {
+    double o[PSH_MAX_OBS];
+    const int O = e->O;
+    int keep = (1 << O) - 1;
+    for (int r = 0; r < O; ++r) o[r] = sim_obs[r];
+    for (int j = w->n_ops - 1; j >= 0; --j) {
+        if (w->ops[j] == PSH_WRAP_OBS_NOISE) {
+            double n[PSH_MAX_OBS];
+            step_normals(w->noise_seed, env, t, 1u, O, n);
+            for (int r = 0; r < O; ++r) o[r] = o[r] + (n[r] * w->obs_noise_std[r] + w->obs_noise_mean[r]);
+        } else if (w->ops[j] == PSH_WRAP_OBS_NORM) {
+            double lo[PSH_MAX_OBS], hi[PSH_MAX_OBS];
+            sim_obs_bounds(e, lo, hi);
+            for (int r = 0; r < O; ++r) {
+                if (!isnan(w->obs_lo[r])) lo[r] = w->obs_lo[r];
+                if (!isnan(w->obs_hi[r])) hi[r] = w->obs_hi[r];
+                o[r] = (o[r] - lo[r]) / (hi[r] - lo[r]) * 2 - 1;
+            }
+        } else if (w->ops[j] == PSH_WRAP_OBS_PARTIAL) {
+            keep = w->obs_keep_mask;
+        }
+    }
+    int n = 0;
+    for (int r = 0; r < O; ++r) if (keep & (1 << r)) out[n++] = o[r];
+    return n;
+}
+
+static int wrap_obs_dim(const psh_wrappers* w, int O) {
+    for (int j = 0; j < w->n_ops; ++j)
+        if (w->ops[j] == PSH_WRAP_OBS_PARTIAL) {
+            int n = 0;
+            for (int r = 0; r < O; ++r) n += (w->obs_keep_mask >> r) & 1;
+            return n;
+        }
+    return O;
+}
+
 /* ---- rollout(): sampling/rollout.py:88-275 ------------------------------------------------------- */
 static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5]) {
     const int S = dims[0], O = dims[1], A = dims[2], P = dims[3], N = d->n_envs, T = d->max_steps;
+    const psh_wrappers* w = &d->wrap;
+    const int OP = wrap_obs_dim(w, O);  /* what the policy sees and `obs` records */
     orc_env e;
     memset(&e, 0, sizeof e);
     e.kind = d->env_kind; e.S = S; e.O = O; e.A = A; e.P = P;
@@ -519,53 +598,68 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
     for (int r = 0; r < P; ++r) dp[r] = d->domain_param[(size_t)r * d->ld_dp + col];
     for (int r = 0; r < d->init_dim; ++r) init[r] = d->init_state[(size_t)r * d->ld_init + i];
     env_reset(&e, &d->task, dp, init, d->init_dim);
-    const double* w = d->policy.params + (size_t)(d->policy.policy_index ? d->policy.policy_index[i] : 0) * d->policy.num_param;
+    const double* pw = d->policy.params + (size_t)(d->policy.policy_index ? d->policy.policy_index[i] : 0) * d->policy.num_param;
+    const uint64_t genv = w->env_offset + (uint64_t)i;
 
-    int delay = 0;
+    int delay = 0, has_delay = 0, new_array = 0;
     double dq[PSH_MAX_DELAY + 1][PSH_MAX_ACT];
-    if (d->act_delay_row >= 0) {
+    for (int j = 0; j < w->n_ops; ++j) {
+        if (w->ops[j] == PSH_WRAP_ACT_DELAY) has_delay = 1;
+        if (w->ops[j] == PSH_WRAP_ACT_NORM || w->ops[j] == PSH_WRAP_ACT_NOISE) new_array = 1;
+    }
+    if (has_delay) {
         /* ActDelayWrapper environment_wrappers/action_delay.py:46-81: queue pre-filled with `delay` zero actions */
-        delay = (int)d->domain_param[(size_t)d->act_delay_row * d->ld_dp + col];
+        delay = w->act_delay_row >= 0 ? (int)d->domain_param[(size_t)w->act_delay_row * d->ld_dp + col] : w->act_delay;
         if (delay < 0) delay = 0;
         if (delay > PSH_MAX_DELAY) delay = PSH_MAX_DELAY;
         memset(dq, 0, sizeof dq);
     }
 
-    double obs[PSH_MAX_OBS], act[PSH_MAX_ACT], ret = 0.;
+    double sim_obs[PSH_MAX_OBS], obs[PSH_MAX_OBS], act[PSH_MAX_ACT], ret = 0.;
     int st = 0, done = 0, k = 0;
-    observe(&e, obs);
+    observe(&e, sim_obs);
+    wrap_obs(w, &e, genv, 0u, sim_obs, obs);
     const int stop_on_done = (d->flags & PSH_F_STOP_ON_DONE) != 0;
     while (!(done && stop_on_done) && e.curr_step < T) {
         int nan = 0;
-        for (int r = 0; r < O; ++r) if (isnan(obs[r])) nan = 1;
-        if (d->obs) for (int r = 0; r < O; ++r) d->obs[((size_t)k * O + r) * N + i] = obs[r];
+        for (int r = 0; r < OP; ++r) if (isnan(obs[r])) nan = 1;
+        if (d->obs) for (int r = 0; r < OP; ++r) d->obs[((size_t)k * OP + r) * N + i] = obs[r];
         if (nan) { st |= PSH_ST_NAN; break; }
-        policy_forward(&d->policy, w, O, A, obs, act);
+        policy_forward(&d->policy, pw, OP, A, obs, act);
         for (int r = 0; r < A; ++r) if (isnan(act[r])) nan = 1;
         if (nan) { st |= PSH_ST_NAN; break; }
-        double rew;
-        if (delay > 0) {
-            /* _process_act (action_delay.py:66-81) queues the array OBJECTS: the action applied now is the
-             * ndarray recorded `delay` steps ago (or the shared zero array), so an in-place dead-zone write of
-             * the inner env lands in that earlier recorded action. */
-            double inner[PSH_MAX_ACT];
-            for (int r = 0; r < A; ++r) dq[delay][r] = act[r];
-            for (int r = 0; r < A; ++r) inner[r] = dq[0][r];
-            for (int q = 0; q < delay; ++q) for (int r = 0; r < A; ++r) dq[q][r] = dq[q + 1][r];
-            rew = env_step(&e, &d->task, inner, d->dt, T, 0, &done, &st);
-            if (d->act && k - delay >= 0)
-                for (int r = 0; r < A; ++r) d->act[((size_t)(k - delay) * A + r) * N + i] = inner[r];
-        } else {
-            rew = env_step(&e, &d->task, act, d->dt, T, 0, &done, &st);
+        /* EnvWrapperAct.step, outermost wrapper first */
+        double inner[PSH_MAX_ACT];
+        for (int r = 0; r < A; ++r) inner[r] = act[r];
+        for (int j = 0; j < w->n_ops; ++j) {
+            if (w->ops[j] == PSH_WRAP_ACT_DELAY && delay > 0) {
+                /* _process_act (action_delay.py:66-81): append, then pop the oldest */
+                for (int r = 0; r < A; ++r) dq[delay][r] = inner[r];
+                for (int r = 0; r < A; ++r) inner[r] = dq[0][r];
+                for (int q = 0; q < delay; ++q) for (int r = 0; r < A; ++r) dq[q][r] = dq[q + 1][r];
+            } else if (w->ops[j] == PSH_WRAP_ACT_NORM) {
+                for (int r = 0; r < A; ++r) inner[r] = e.a_lo[r] + (inner[r] + 1) * (e.a_hi[r] - e.a_lo[r]) / 2;
+            } else if (w->ops[j] == PSH_WRAP_ACT_NOISE) {
+                double n[PSH_MAX_ACT];
+                step_normals(w->noise_seed, genv, (uint32_t)k, 2u, A, n);
+                for (int r = 0; r < A; ++r) inner[r] = inner[r] + (n[r] * w->act_noise_std[r] + w->act_noise_mean[r]);
+            }
         }
+        double rew = env_step(&e, &d->task, inner, d->dt, T, 0, &done, &st);
+        /* The simulation may have written into the array it was given (QBB dead zone).  Without an array-creating
+         * wrapper that array is the policy's output of `delay` steps ago (ActDelayWrapper queues the array
+         * OBJECTS), which the rollout has recorded; with one, the recorded actions stay untouched. */
         if (d->act) for (int r = 0; r < A; ++r) d->act[((size_t)k * A + r) * N + i] = act[r];
+        if (d->act && !new_array && k - delay >= 0)
+            for (int r = 0; r < A; ++r) d->act[((size_t)(k - delay) * A + r) * N + i] = inner[r];
         if (d->rew) d->rew[(size_t)k * N + i] = rew;
         ret += rew;
-        observe(&e, obs);
+        observe(&e, sim_obs);
         ++k;
+        wrap_obs(w, &e, genv, (uint32_t)k, sim_obs, obs);
         if (st & PSH_ST_NAN) break;
     }
-    if (d->obs) for (int r = 0; r < O; ++r) d->obs[((size_t)k * O + r) * N + i] = obs[r];
+    if (d->obs) for (int r = 0; r < OP; ++r) d->obs[((size_t)k * OP + r) * N + i] = obs[r];
     d->ret[i] = ret;
     d->length[i] = k;
     d->status[i] = st;
@@ -575,7 +669,7 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
 int orc_rollout(const psh_rollout_desc* d, int n_threads) {
     int32_t dims[5];
     if (orc_env_dims(d->env_kind, dims)) return PSH_ERR_ARG;
-    if (d->policy.num_param != orc_policy_num_param(&d->policy, dims[1], dims[2])) return PSH_ERR_ARG;
+    if (d->policy.num_param != orc_policy_num_param(&d->policy, wrap_obs_dim(&d->wrap, dims[1]), dims[2])) return PSH_ERR_ARG;
     (void)n_threads;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);

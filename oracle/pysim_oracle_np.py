@@ -425,10 +425,163 @@ class FNNPolicyNp:
 
 
 # -------------------------------------------------------------------------------------------- rollout
+# ---- environment wrappers, environment_wrappers/*.py, as nested objects like the reference's ------------------
+M32 = 0xFFFFFFFF
+
+
+def philox4x32_10(ctr, key):
+    """ Philox4x32-10 (the product's counter-based generator; the reference draws from NumPy's global one) """
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = 0xD2511F53*c0, 0xCD9E8D57*c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+def step_normals(seed, env, t, stream, n):
+    """ n standard normals for (seed, env, step, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p """
+    out = np.zeros(n)
+    for p in range((n + 1)//2):
+        o = philox4x32_10((env & M32, (env >> 32) & M32, t, stream + 16*p), (seed & M32, (seed >> 32) & M32))
+        ua = ((o[0] >> 5)*67108864.0 + (o[1] >> 6))*(1.0/9007199254740992.0)
+        ub = ((o[2] >> 5)*67108864.0 + (o[3] >> 6))*(1.0/9007199254740992.0)
+        r = np.sqrt(-2.0*np.log(1.0 - ua))
+        out[2*p] = r*np.cos(2.0*PI*ub)
+        if 2*p + 1 < n:
+            out[2*p + 1] = r*np.sin(2.0*PI*ub)
+    return out
+
+
+class NpWrapper:
+    """ EnvWrapper (environment_wrappers/base.py:29-141): forwards everything to the wrapped env """
+
+    def __init__(self, wrapped):
+        self.wrapped = wrapped
+
+    def __getattr__(self, name):  # curr_step, max_steps, a_lo, a_hi, state, ...
+        return getattr(self.__dict__['wrapped'], name)
+
+    @property
+    def sim(self):
+        return self.wrapped.sim if isinstance(self.wrapped, NpWrapper) else self.wrapped
+
+    def obs_bounds(self):
+        return self.wrapped.obs_bounds()
+
+    def reset(self, init_state, domain_param=None):
+        return self.wrapped.reset(init_state, domain_param)
+
+    def step(self, act):
+        return self.wrapped.step(act)
+
+
+def _sim_obs_bounds(env: NpEnv):
+    """ observation spaces: pysim/quanser_qube.py:25-33, quanser_cartpole.py:45-50, others = state space """
+    if env.kind == 'qq':
+        m = np.array([1., 1., 1., 1., np.inf, np.inf])
+        return -m, m
+    if env.kind in ('qcp-su', 'qcp-st'):
+        m = np.array([env.dp['l_rail']/2., 1., 1., np.inf, np.inf])
+        return -m, m
+    return env.s_lo.copy(), env.s_hi.copy()
+
+
+NpEnv.obs_bounds = _sim_obs_bounds
+
+
+class NpActNorm(NpWrapper):  # action_normalization.py:10-22
+    def step(self, act):
+        lb, ub = self.wrapped.a_lo, self.wrapped.a_hi
+        return self.wrapped.step(lb + (act + 1)*(ub - lb)/2)
+
+
+class NpActDelay(NpWrapper):  # action_delay.py:12-81
+    def __init__(self, wrapped, delay=0):
+        super().__init__(wrapped)
+        self.delay, self.queue = delay, []
+
+    def reset(self, init_state, domain_param=None):
+        if domain_param is not None:
+            self.delay = int(domain_param.get('act_delay', self.delay))
+            domain_param = {k: v for k, v in domain_param.items() if k != 'act_delay'}
+        self.queue = [np.zeros(self.sim.a_lo.shape)]*self.delay
+        return self.wrapped.reset(init_state, domain_param)
+
+    def step(self, act):
+        if self.delay != 0:
+            self.queue.append(act)
+            act = self.queue.pop(0)
+        return self.wrapped.step(act)
+
+
+class NpNoise(NpWrapper):
+    def __init__(self, wrapped, mean, std, seed, env_id):
+        super().__init__(wrapped)
+        self.mean, self.std, self.seed, self.env_id = np.asarray(mean, float), np.asarray(std, float), seed, env_id
+
+
+class NpActNoise(NpNoise):  # action_noise.py:42-47; step counter = the simulation's curr_step before the step
+    def step(self, act):
+        noise = step_normals(self.seed, self.env_id, self.sim.curr_step, 2, act.shape[0])*self.std + self.mean
+        return self.wrapped.step(act + noise)
+
+
+class NpObsNoise(NpNoise):  # observation_noise.py:34-39; one draw per observation, indexed by its time step
+    def _process(self, obs):
+        return obs + (step_normals(self.seed, self.env_id, self.sim.curr_step, 1, obs.shape[0])*self.std + self.mean)
+
+    def reset(self, init_state, domain_param=None):
+        return self._process(self.wrapped.reset(init_state, domain_param))
+
+    def step(self, act):
+        obs, rew, done, info = self.wrapped.step(act)
+        return self._process(obs), rew, done, info
+
+
+class NpObsNorm(NpWrapper):  # observation_normalization.py:73-86; lo/hi: explicit bounds, NaN = the env's own
+    def __init__(self, wrapped, lo=None, hi=None):
+        super().__init__(wrapped)
+        self.lo, self.hi = lo, hi
+
+    def _process(self, obs):
+        lb, ub = self.wrapped.obs_bounds()
+        if self.lo is not None:
+            lb = np.where(np.isnan(self.lo), lb, self.lo)
+        if self.hi is not None:
+            ub = np.where(np.isnan(self.hi), ub, self.hi)
+        return (obs - lb)/(ub - lb)*2 - 1
+
+    def reset(self, init_state, domain_param=None):
+        return self._process(self.wrapped.reset(init_state, domain_param))
+
+    def step(self, act):
+        obs, rew, done, info = self.wrapped.step(act)
+        return self._process(obs), rew, done, info
+
+
+class NpObsPartial(NpWrapper):  # observation_partial.py:43-46
+    def __init__(self, wrapped, keep):
+        super().__init__(wrapped)
+        self.keep = np.asarray(keep, dtype=bool)
+
+    def obs_bounds(self):
+        lo, hi = self.wrapped.obs_bounds()
+        return lo[self.keep], hi[self.keep]
+
+    def reset(self, init_state, domain_param=None):
+        return self.wrapped.reset(init_state, domain_param)[self.keep]
+
+    def step(self, act):
+        obs, rew, done, info = self.wrapped.step(act)
+        return obs[self.keep], rew, done, info
+
+
 def rollout_np(env: NpEnv, policy, init_state, domain_param=None, stop_on_done=True, act_delay=0):
     """ sampling/rollout.py:88-275 (+ ActDelayWrapper environment_wrappers/action_delay.py:55-81) """
     obs = env.reset(init_state, domain_param)
-    queue = [np.zeros(env.a_lo.shape)]*act_delay
+    queue = [np.zeros(env.a_lo.shape)]*act_delay  # legacy shortcut for a single outermost ActDelayWrapper
     obs_hist, act_hist, rew_hist, t_hist = [], [], [], []
     done = False
     while not (done and stop_on_done) and env.curr_step < env.max_steps:
@@ -449,4 +602,4 @@ def rollout_np(env: NpEnv, policy, init_state, domain_param=None, stop_on_done=T
         obs = obs_next
     obs_hist.append(obs)
     return dict(observations=np.stack(obs_hist), actions=np.stack(act_hist), rewards=np.array(rew_hist),
-                t=np.array(t_hist), length=len(rew_hist), ret=float(np.sum(rew_hist)), final_state=env.state.copy())
+                t=np.array(t_hist), length=len(rew_hist), ret=float(np.sum(rew_hist)), final_state=np.array(env.state).copy())

@@ -4,6 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
+PSH_VERSION = 101
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -13,6 +14,7 @@ PSH_MAX_WIDTH = 64
 PSH_MAX_FEATS = 8
 PSH_MAX_DISTR = 32
 PSH_MAX_DELAY = 32
+PSH_MAX_WRAP = 6
 
 PSH_OK, PSH_ERR_ARG, PSH_ERR_HIP, PSH_ERR_NODEV, PSH_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -26,6 +28,7 @@ NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF = 1, 2, 4
 ST_NAN, ST_FAILED, ST_TIMEOUT = 1, 2, 4
 DISTR_CONST, DISTR_NORMAL, DISTR_UNIFORM, DISTR_BERNOULLI = range(4)
+WRAP_ACT_NORM, WRAP_ACT_DELAY, WRAP_ACT_NOISE, WRAP_OBS_NOISE, WRAP_OBS_NORM, WRAP_OBS_PARTIAL = range(1, 7)
 
 # (S, O, A, P, init_dim) per env kind
 ENV_DIMS = {ENV_QQ: (4, 6, 1, 10, 4), ENV_QCP_SU: (4, 5, 1, 14, 4), ENV_QCP_ST: (4, 5, 1, 14, 4),
@@ -55,13 +58,24 @@ class PshPolicy(C.Structure):
     ]
 
 
+class PshWrappers(C.Structure):
+    _fields_ = [
+        ('n_ops', C.c_int32), ('ops', C.c_int32*PSH_MAX_WRAP), ('act_delay', C.c_int32), ('act_delay_row', C.c_int32),
+        ('obs_keep_mask', C.c_int32), ('pad_', C.c_int32*2),
+        ('noise_seed', C.c_uint64), ('env_offset', C.c_uint64),
+        ('act_noise_mean', C.c_double*PSH_MAX_ACT), ('act_noise_std', C.c_double*PSH_MAX_ACT),
+        ('obs_noise_mean', C.c_double*PSH_MAX_OBS), ('obs_noise_std', C.c_double*PSH_MAX_OBS),
+        ('obs_lo', C.c_double*PSH_MAX_OBS), ('obs_hi', C.c_double*PSH_MAX_OBS),
+    ]
+
+
 class PshRolloutDesc(C.Structure):
     _fields_ = [
         ('env_kind', C.c_int32), ('n_envs', C.c_int32), ('max_steps', C.c_int32), ('flags', C.c_int32),
         ('dt', C.c_double),
         ('init_state', C.c_void_p), ('init_dim', C.c_int32), ('ld_init', C.c_int32),
-        ('domain_param', C.c_void_p), ('dp_index', C.c_void_p), ('ld_dp', C.c_int32), ('act_delay_row', C.c_int32),
-        ('task', PshTask), ('policy', PshPolicy),
+        ('domain_param', C.c_void_p), ('dp_index', C.c_void_p), ('ld_dp', C.c_int32), ('pad_', C.c_int32),
+        ('task', PshTask), ('policy', PshPolicy), ('wrap', PshWrappers),
         ('ret', C.c_void_p), ('length', C.c_void_p), ('status', C.c_void_p), ('final_state', C.c_void_p),
         ('obs', C.c_void_p), ('act', C.c_void_p), ('rew', C.c_void_p),
         ('stream', C.c_void_p),

@@ -50,6 +50,11 @@ template <> struct Env<PSH_ENV_QQ> {
         for (int i = 0; i < 4; ++i) { lo[i] = -m[i]; hi[i] = m[i]; }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -max_volt; hi[0] = max_volt; }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const {  // quanser_qube.py:25-33
+        const double inf = __builtin_inf();
+        for (int i = 0; i < 4; ++i) { lo[i] = -1.; hi[i] = 1.; }
+        lo[4] = lo[5] = -inf; hi[4] = hi[5] = inf;
+    }
     PSH_DEV void refresh() { psh_sincos(s[0], &sth, &cth); psh_sincos(s[1], &sal, &cal); }
     PSH_DEV void reset(const double* init, int, bool) {
         for (int i = 0; i < 4; ++i) s[i] = init[i];
@@ -122,6 +127,11 @@ template <int KIND> struct EnvQCP {
         }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -8.; hi[0] = 8.; }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const {  // quanser_cartpole.py:45-50
+        const double inf = __builtin_inf();
+        hi[0] = l_rail / 2.; hi[1] = 1.; hi[2] = 1.; hi[3] = inf; hi[4] = inf;
+        for (int i = 0; i < 5; ++i) lo[i] = -hi[i];
+    }
     PSH_DEV void refresh() { psh_sincos(s[1], &sth, &cth); }
     PSH_DEV void reset(const double* init, int, bool) {
         for (int i = 0; i < 4; ++i) s[i] = init[i];
@@ -194,6 +204,7 @@ template <> struct Env<PSH_ENV_QBB> {
         for (int i = 0; i < 8; ++i) { lo[i] = -m[i]; hi[i] = m[i]; }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = lo[1] = -3.0; hi[0] = hi[1] = 3.0; }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const { state_bounds(lo, hi); }  // quanser_ball_balancer.py:73
     PSH_DEV void refresh() {}
     PSH_DEV void reset(const double* init, int init_dim, bool simplified) {
         if (init_dim == 4) {
@@ -265,6 +276,7 @@ template <> struct Env<PSH_ENV_BOB> {
         const double m = l_beam / 2. * g * 3.;
         lo[0] = -m; hi[0] = m;
     }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const { state_bounds(lo, hi); }  // ball_on_beam.py:32
     PSH_DEV void refresh() {}
     PSH_DEV void reset(const double* init, int, bool) { for (int i = 0; i < 4; ++i) s[i] = init[i]; }
     PSH_DEV void observe(double* o) const { for (int i = 0; i < 4; ++i) o[i] = s[i]; }
@@ -294,6 +306,7 @@ template <> struct Env<PSH_ENV_OMO> {
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const { lo[0] = -1.; hi[0] = 1.; lo[1] = -10.; hi[1] = 10.; }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -k; hi[0] = k; }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const { state_bounds(lo, hi); }  // one_mass_oscillator.py:39
     PSH_DEV void refresh() {}
     PSH_DEV void reset(const double* init, int, bool) { s[0] = init[0]; s[1] = init[1]; }
     PSH_DEV void observe(double* o) const { o[0] = s[0]; o[1] = s[1]; }

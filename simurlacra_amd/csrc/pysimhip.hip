@@ -1,8 +1,10 @@
 // libpysimhip.so — kernels and C ABI (include/pysimhip.h) of the MI355X batched rollout engine.
 //
 // Kernels (all gfx950, wave64):
-//   k_rollout_linear<KIND, PER_ENV>  fused reset + T x (LinearPolicy forward, SimPyEnv.step); one lane per env
-//   k_rollout_fnn<KIND, HP>          same with an FNNPolicy: the hidden layers run on v_mfma_f64_16x16x4_f64 with
+//   k_rollout_linear<KIND, PER_ENV, WRAP>  fused reset + T x (LinearPolicy forward, SimPyEnv.step); one lane per env;
+//                                    WRAP adds the fused environment wrappers (action/observation normalisation,
+//                                    delay, noise, partial observation)
+//   k_rollout_fnn<KIND, HP, FINE, WRAP>  same with an FNNPolicy: the hidden layers run on v_mfma_f64_16x16x4_f64 with
 //                                    the weights as the A operand and 16 environments as the columns of B, so a
 //                                    layer's accumulator is directly the next layer's B operand
 //   k_reset / k_step                 SimPyEnv.reset / SimPyEnv.step for caller-supplied actions
@@ -11,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -26,6 +29,8 @@ struct psh_ctx {
     size_t wfrag_doubles;
     double* plate;       // QBB plate angles of the IK prologue [2, N], grown on demand
     size_t plate_doubles;
+    double* delay_q;     // ActDelay ring buffers of the resident lanes, grown on demand
+    size_t delay_q_doubles;
     unsigned int* queue; // work-queue counter of the rollout kernels
     double* tanh_tab;    // [tanh(j/256), j = 0..5120 (psh_tanh8)][tanh(j/64), j = 0..1280 (psh_tanh_tab)]
     int num_cus;
@@ -76,7 +81,11 @@ struct RolloutArgs {
     const double* init_state; long ld_init;
     const double* domain_param; const int* dp_index; long ld_dp;
     psh_task task;
+    psh_wrappers wrap;     // directly behind `task`: the two are staged into LDS as one block
     psh_policy pol;
+    int obs_dim;           // entries of the observation the policy sees (all, or those kept by OBS_PARTIAL)
+    double* delay_q;       // ACT_DELAY: ring buffers [PSH_MAX_DELAY][A][n_lanes], one column per resident lane
+    long n_lanes;
     int num_feat;          // LINEAR: total feature count F
     int lds_doubles;       // FNN: doubles of the packed weight image
     const double* wfrag;   // FNN: packed weight image (device)
@@ -89,7 +98,9 @@ struct RolloutArgs {
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
 // pulled into scalar registers for the whole loop and spill.
-constexpr int TASK_DOUBLES = (sizeof(psh_task) + 7) / 8;
+static_assert(sizeof(psh_task) % 8 == 0 && sizeof(psh_wrappers) % 8 == 0, "staged as doubles");
+static_assert(offsetof(RolloutArgs, wrap) == offsetof(RolloutArgs, task) + sizeof(psh_task), "staged as one block");
+constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
 constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
 
 __device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
@@ -124,29 +135,46 @@ PSH_DEV double feat_apply(int id, double x) {
 }
 
 // ------------------------------------------------------------------------------------------ one lane = one env
-template <int KIND> struct Lane {
+// n standard normals for (seed, env, step, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p
+template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double* out) {
+#pragma unroll
+    for (int p = 0; 2 * p < N; ++p) {
+        double ua, ub, sn, cs;
+        psh_draw2(seed, env, t, stream + 16u * p, ua, ub);
+        const double r = sqrt(-2.0 * log(1.0 - ua));
+        sincos(2.0 * PSH_PI * ub, &sn, &cs);
+        out[2 * p] = r * cs;
+        if (2 * p + 1 < N) out[2 * p + 1] = r * sn;
+    }
+}
+
+// WRAP = true adds the fused environment wrappers (psh_wrappers) around the simulation; the bare variant carries
+// none of that code or state.
+template <int KIND, bool WRAP> struct Lane {
     using E = Env<KIND>;
     E e;
     double c_max, ret;
     long i;           // env this lane currently runs, -1: none
     int curr_step, yielded, st, k;
+    int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
     bool done, live;  // live: this lane still has steps to execute
     bool exhausted;   // the work queue had nothing left for this lane
+    bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
 
     PSH_DEV void init() { i = -1; live = false; exhausted = false; }
 
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
     // an env has no influence on its results.
-    PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task) {
-        if (i >= 0 && !live) { store(a); i = -1; }
+    PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+        if (i >= 0 && !live) { store(a, wrap); i = -1; }
         if (i < 0 && !exhausted) {
             const unsigned int nxt = atomicAdd(a.queue, 1u);
-            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a, task); } else { exhausted = true; }
+            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a, task, wrap); } else { exhausted = true; }
         }
     }
 
-    PSH_DEV void load(const RolloutArgs& a, const psh_task& task) {
+    PSH_DEV void load(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
         const long col = a.dp_index ? (long)a.dp_index[i] : i;
         const DpCol p{a.domain_param, a.ld_dp, col};
         e.setup(p);
@@ -161,31 +189,129 @@ template <int KIND> struct Lane {
         }
         ret = 0.; curr_step = 0; yielded = 0; st = 0; k = 0; done = false;
         live = a.max_steps > 0;
+        if constexpr (WRAP) {
+            bool has_delay = false, new_array = false;
+            for (int j = 0; j < wrap.n_ops; ++j) {
+                has_delay = has_delay || wrap.ops[j] == PSH_WRAP_ACT_DELAY;
+                new_array = new_array || wrap.ops[j] == PSH_WRAP_ACT_NORM || wrap.ops[j] == PSH_WRAP_ACT_NOISE;
+            }
+            delay = 0; qpos = 0;
+            if (has_delay) {  // ActDelayWrapper.reset / _load_domain_param (action_delay.py:46-64)
+                delay = wrap.act_delay_row >= 0 ? (int)a.domain_param[wrap.act_delay_row * a.ld_dp + col] : wrap.act_delay;
+                delay = delay < 0 ? 0 : (delay > PSH_MAX_DELAY ? PSH_MAX_DELAY : delay);
+            }
+            rec_alias = !new_array;
+        }
+    }
+
+    // EnvWrapperObs.reset/step (environment_wrappers/base.py:216-231): the simulation's observation through the
+    // observation wrappers, innermost first; `out` receives the kept entries in order, zero padded
+    PSH_DEV void wrapped_obs(const RolloutArgs& a, const psh_wrappers& wrap, uint32_t t, double* out) const {
+        double o[E::O];
+        e.observe(o);
+        int keep = (1 << E::O) - 1;
+        for (int j = wrap.n_ops - 1; j >= 0; --j) {
+            const int op = wrap.ops[j];
+            if (op == PSH_WRAP_OBS_NOISE) {
+                double n[E::O];
+                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, t, 1u, n);
+#pragma unroll
+                for (int r = 0; r < E::O; ++r) o[r] = o[r] + (n[r] * wrap.obs_noise_std[r] + wrap.obs_noise_mean[r]);
+            } else if (op == PSH_WRAP_OBS_NORM) {
+                double lo[E::O], hi[E::O];
+                e.obs_bounds(lo, hi);
+#pragma unroll
+                for (int r = 0; r < E::O; ++r) {
+                    const double l = wrap.obs_lo[r], h = wrap.obs_hi[r];
+                    lo[r] = (l != l) ? lo[r] : l;
+                    hi[r] = (h != h) ? hi[r] : h;
+                    o[r] = (o[r] - lo[r]) / (hi[r] - lo[r]) * 2 - 1;
+                }
+            } else if (op == PSH_WRAP_OBS_PARTIAL) {
+                keep = wrap.obs_keep_mask;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) out[r] = 0.;
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) {
+            if (keep & (1 << r)) {
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) out[q] = (q == n) ? o[r] : out[q];  // out[n] = o[r] without dynamic indexing
+                n += 1;
+            }
+        }
     }
 
     // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
-    PSH_DEV void pre_policy(const RolloutArgs& a, double* obs) {
-        e.observe(obs);
+    PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs) {
+        if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+        const int Oe = WRAP ? a.obs_dim : E::O;
         bool nan = false;
 #pragma unroll
-        for (int r = 0; r < E::O; ++r) nan = nan || (obs[r] != obs[r]);
+        for (int r = 0; r < E::O; ++r) nan = nan || (r < Oe && obs[r] != obs[r]);
         if (a.obs) {
 #pragma unroll
-            for (int r = 0; r < E::O; ++r) a.obs[((long)k * E::O + r) * a.n_envs + i] = obs[r];
+            for (int r = 0; r < E::O; ++r)
+                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
         }
         if (nan) { st |= PSH_ST_NAN; live = false; }
     }
 
-    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, double* act) {
+    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act) {
         bool nan = false;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
         if (nan) { st |= PSH_ST_NAN; live = false; return; }
-        const double rew = env_step<KIND>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false,
-                                          (a.flags & PSH_F_SIMPLIFIED_DYN) != 0, done, st);
-        if (a.act) {
+        const bool simplified = (a.flags & PSH_F_SIMPLIFIED_DYN) != 0;
+        double rew;
+        if constexpr (WRAP) {
+            // EnvWrapperAct.step (environment_wrappers/base.py:168-174), outermost wrapper first
+            double inner[E::A];
 #pragma unroll
-            for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+            for (int r = 0; r < E::A; ++r) inner[r] = act[r];
+            for (int j = 0; j < wrap.n_ops; ++j) {
+                const int op = wrap.ops[j];
+                if (op == PSH_WRAP_ACT_DELAY && delay > 0) {  // FIFO as a ring: the slot written now is read `delay` steps on
+                    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) {
+                        double* q = a.delay_q + ((long)qpos * E::A + r) * a.n_lanes + slot;
+                        const double old = (k >= delay) ? *q : 0.;
+                        *q = inner[r];
+                        inner[r] = old;
+                    }
+                    qpos = (qpos + 1 == delay) ? 0 : qpos + 1;
+                } else if (op == PSH_WRAP_ACT_NORM) {
+                    double lo[E::A], hi[E::A];
+                    e.act_bounds(lo, hi);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
+                } else if (op == PSH_WRAP_ACT_NOISE) {
+                    double n[E::A];
+                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 2u, n);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
+                }
+            }
+            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+                // ActDelayWrapper queues the caller's array objects: without an array-creating wrapper the simulation
+                // wrote its dead zone (QBB) into the action recorded `delay` steps ago
+                if (rec_alias && k - delay >= 0) {
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) a.act[((long)(k - delay) * E::A + r) * a.n_envs + i] = inner[r];
+                }
+            }
+        } else {
+            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+            }
         }
         if (a.rew) a.rew[(long)k * a.n_envs + i] = rew;
         ret += rew;
@@ -194,12 +320,14 @@ template <int KIND> struct Lane {
         if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
     }
 
-    PSH_DEV void store(const RolloutArgs& a) {
+    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap) {
         if (a.obs) {  // final observation
             double obs[E::O];
-            e.observe(obs);
+            if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+            const int Oe = WRAP ? a.obs_dim : E::O;
 #pragma unroll
-            for (int r = 0; r < E::O; ++r) a.obs[((long)k * E::O + r) * a.n_envs + i] = obs[r];
+            for (int r = 0; r < E::O; ++r)
+                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
         }
         a.ret[i] = ret;
         a.length[i] = k;
@@ -213,26 +341,28 @@ template <int KIND> struct Lane {
 
 // ------------------------------------------------------------------------------------- LinearPolicy rollouts
 // PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] of params.
-template <int KIND, bool PER_ENV>
-__global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
+template <int KIND, bool PER_ENV, bool WRAP>
+__global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS;
     __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
     double* const lds_w = lds_lin;
     const psh_task& task = *reinterpret_cast<const psh_task*>(lds_lin + W_DOUBLES);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(lds_lin + W_DOUBLES + sizeof(psh_task) / 8);
     const int F = a.num_feat;
+    const int Oe = WRAP ? a.obs_dim : E::O;  // observation entries the policy sees
     if (!PER_ENV) {
         for (int j = threadIdx.x; j < E::A * F; j += blockDim.x) lds_w[j] = a.pol.params[j];
     }
     stage_task(a, lds_lin + W_DOUBLES);
     __syncthreads();
-    Lane<KIND> L;
+    Lane<KIND, WRAP> L;
     L.init();
     const double* w = lds_w;
     long w_env = -1;
     for (;;) {
         asm volatile("" ::: "memory");  // keep the LDS constants out of registers across iterations
-        L.turnover(a, task);
+        L.turnover(a, task, wrap);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         if (L.i < 0) continue;
         if (PER_ENV && w_env != L.i) {
@@ -240,7 +370,7 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
             w_env = L.i;
         }
         double obs[E::O], act[E::A];
-        L.pre_policy(a, obs);
+        L.pre_policy(a, wrap, obs);
         if (!L.live) continue;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) act[r] = 0.;
@@ -254,14 +384,15 @@ __global__ __launch_bounds__(256) void k_rollout_linear(const RolloutArgs a) {
             } else {
 #pragma unroll
                 for (int q = 0; q < E::O; ++q) {
+                    if (WRAP && q >= Oe) break;
                     const double v = feat_apply(id, obs[q]);
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * v;
                 }
-                n += E::O;
+                n += Oe;
             }
         }
-        L.post_policy(a, task, act);
+        L.post_policy(a, task, wrap, act);
     }
 }
 
@@ -310,7 +441,7 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
     }
 }
 
-template <int KIND, int HP, bool FINE>
+template <int KIND, int HP, bool FINE, bool WRAP>
 __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
@@ -322,23 +453,24 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_lds);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_lds + sizeof(psh_task) / 8);
 
     for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
     for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
     stage_task(a, task_lds);
     __syncthreads();
 
-    Lane<KIND> L;
+    Lane<KIND, WRAP> L;
     L.init();
 
     const int n_hidden = a.pol.n_hidden;
     for (;;) {
-        L.turnover(a, task);
+        L.turnover(a, task, wrap);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         double obs[OP], act[E::A];
 #pragma unroll
         for (int r = 0; r < OP; ++r) obs[r] = 0.;
-        if (L.live) L.pre_policy(a, obs);
+        if (L.live) L.pre_policy(a, wrap, obs);
         if (!__any(L.live)) continue;
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
 #pragma unroll
@@ -405,7 +537,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 if (q == tile) act[r] = p;
             }
         }
-        if (L.live) L.post_policy(a, task, act);
+        if (L.live) L.post_policy(a, task, wrap, act);
     }
 }
 
@@ -719,6 +851,7 @@ extern "C" void psh_destroy(psh_ctx* c) {
     (void)hipDeviceSynchronize();
     if (c->wfrag) (void)hipFree(c->wfrag);
     if (c->plate) (void)hipFree(c->plate);
+    if (c->delay_q) (void)hipFree(c->delay_q);
     if (c->queue) (void)hipFree(c->queue);
     if (c->tanh_tab) (void)hipFree(c->tanh_tab);
     (void)hipEventDestroy(c->ev0);
@@ -745,35 +878,85 @@ static int check_task(psh_ctx* c, const psh_task& t, int S) {
     return PSH_OK;
 }
 
+// The fused wrappers of a rollout: every op known and used once, sizes in range.  Yields the policy's input dimension.
+static int check_wrap(psh_ctx* c, const psh_wrappers& w, int O, int* obs_dim, bool* has_delay) {
+    *obs_dim = O;
+    *has_delay = false;
+    if (w.n_ops < 0 || w.n_ops > PSH_MAX_WRAP) { set_err(c, "wrap.n_ops outside 0..PSH_MAX_WRAP"); return PSH_ERR_ARG; }
+    unsigned seen = 0;
+    for (int j = 0; j < w.n_ops; ++j) {
+        const int op = w.ops[j];
+        if (op < PSH_WRAP_ACT_NORM || op > PSH_WRAP_OBS_PARTIAL) { set_err(c, "unknown wrapper op"); return PSH_ERR_ARG; }
+        if (seen & (1u << op)) { set_err(c, "each wrapper kind can be fused once"); return PSH_ERR_UNSUPPORTED; }
+        seen |= 1u << op;
+        if (op == PSH_WRAP_ACT_DELAY) {
+            *has_delay = true;
+            if (w.act_delay_row < 0 && (w.act_delay < 0 || w.act_delay > PSH_MAX_DELAY)) {
+                set_err(c, "act_delay outside 0..PSH_MAX_DELAY");
+                return PSH_ERR_ARG;
+            }
+        }
+        if (op == PSH_WRAP_OBS_PARTIAL) {
+            const int m = w.obs_keep_mask;
+            if (m <= 0 || m >= (1 << O)) {
+                if (m != (1 << O) - 1) { set_err(c, "obs_keep_mask must select 1..O observations"); return PSH_ERR_ARG; }
+            }
+            *obs_dim = __builtin_popcount((unsigned)m);
+        }
+    }
+    return PSH_OK;
+}
+
+// Persistent launch of a rollout kernel: grid from the occupancy query, the ActDelay ring buffers sized to it.
+template <class K>
+static int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_bytes, RolloutArgs& a, int act_dim, bool need_delay_q,
+                             hipStream_t st) {
+    if (lds_bytes)
+        PSH_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, a.n_envs);
+    a.n_lanes = (long)grid * block;
+    if (need_delay_q) {
+        const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes);
+        if (rc != PSH_OK) return rc;
+        a.delay_q = c->delay_q;
+    }
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, st, a);
+    PSH_HIP(c, hipGetLastError());
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
+    return PSH_OK;
+}
+
 template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, RolloutArgs& a, hipStream_t st) {
     using E = Env<KIND>;
     const psh_policy& p = d->policy;
     const bool per_env = p.policy_index != nullptr && p.n_policies > 1;
+    int Oe = E::O;
+    bool has_delay = false;
+    {
+        const int rc = check_wrap(c, d->wrap, E::O, &Oe, &has_delay);
+        if (rc != PSH_OK) return rc;
+    }
+    const bool wrapped = d->wrap.n_ops > 0;
+    a.obs_dim = Oe;
     if (p.kind == PSH_POL_LINEAR) {
         if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }
         int F = 0;
         for (int f = 0; f < p.n_feats; ++f) {
             if (p.feats[f] < 0 || p.feats[f] > PSH_FEAT_SINCOS) { set_err(c, "unknown feature id"); return PSH_ERR_ARG; }
-            F += (p.feats[f] == PSH_FEAT_CONST) ? 1 : E::O;
+            F += (p.feats[f] == PSH_FEAT_CONST) ? 1 : Oe;
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;
-        const dim3 block(256);
-        if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
-        if (per_env) {
-            const dim3 grid(persistent_grid(c, k_rollout_linear<KIND, true>, 256, 0, d->n_envs));
-            hipLaunchKernelGGL((k_rollout_linear<KIND, true>), grid, block, 0, st, a);
-        } else {
-            const dim3 grid(persistent_grid(c, k_rollout_linear<KIND, false>, 256, 0, d->n_envs));
-            hipLaunchKernelGGL((k_rollout_linear<KIND, false>), grid, block, 0, st, a);
-        }
-        PSH_HIP(c, hipGetLastError());
-        if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
-        return PSH_OK;
+        if (per_env)
+            return wrapped ? launch_persistent(c, k_rollout_linear<KIND, true, true>, 256, 0, a, E::A, has_delay, st)
+                           : launch_persistent(c, k_rollout_linear<KIND, true, false>, 256, 0, a, E::A, false, st);
+        return wrapped ? launch_persistent(c, k_rollout_linear<KIND, false, true>, 256, 0, a, E::A, has_delay, st)
+                       : launch_persistent(c, k_rollout_linear<KIND, false, false>, 256, 0, a, E::A, false, st);
     }
     if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
     if (p.n_hidden < 1 || p.n_hidden > PSH_MAX_HIDDEN) { set_err(c, "FNNPolicy needs 1..4 hidden layers"); return PSH_ERR_ARG; }
-    int hmax = 0, np = 0, last = E::O;
+    int hmax = 0, np = 0, last = Oe;
     for (int l = 0; l < p.n_hidden; ++l) {
         const int h = p.hidden[l];
         if (h < 1 || h > PSH_MAX_WIDTH) { set_err(c, "hidden sizes must be within 1..64"); return PSH_ERR_ARG; }
@@ -792,7 +975,7 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
         const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total);
         if (rc != PSH_OK) return rc;
     }
-    hipLaunchKernelGGL(k_pack_fnn, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, (int)E::O, (int)E::A,
+    hipLaunchKernelGGL(k_pack_fnn, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, Oe, (int)E::A,
                        HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
@@ -804,23 +987,14 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
     a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
     const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
     if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
-    const dim3 block(BLOCK);
-    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
-#define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                   \
-    do {                                                                                                             \
-        PSH_HIP(c, hipFuncSetAttribute((const void*)k_rollout_fnn<KIND, HP_, FINE_>,                                  \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                 \
-        const dim3 grid(persistent_grid(c, k_rollout_fnn<KIND, HP_, FINE_>, BLOCK, lds_bytes, d->n_envs));            \
-        hipLaunchKernelGGL((k_rollout_fnn<KIND, HP_, FINE_>), grid, block, lds_bytes, st, a);                         \
-    } while (0)
-    if (HP == 16) PSH_LAUNCH_FNN(16, true);
-    else if (HP == 32) PSH_LAUNCH_FNN(32, true);
-    else if (fine) PSH_LAUNCH_FNN(64, true);
-    else PSH_LAUNCH_FNN(64, false);
+#define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                       \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true>, BLOCK, lds_bytes, a, E::A, has_delay, st)     \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false>, BLOCK, lds_bytes, a, E::A, false, st))
+    if (HP == 16) return PSH_LAUNCH_FNN(16, true);
+    if (HP == 32) return PSH_LAUNCH_FNN(32, true);
+    if (fine) return PSH_LAUNCH_FNN(64, true);
+    return PSH_LAUNCH_FNN(64, false);
 #undef PSH_LAUNCH_FNN
-    PSH_HIP(c, hipGetLastError());
-    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
-    return PSH_OK;
 }
 
 extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
@@ -836,7 +1010,6 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     const bool full_state = d->init_dim == dm[0];
     if (!(d->init_dim == dm[4] || full_state)) { set_err(c, "init_dim must be the init-space or the state dimension"); return PSH_ERR_ARG; }
     if (d->ld_init < d->n_envs || d->ld_dp < 1 || (!d->dp_index && d->ld_dp < d->n_envs)) { set_err(c, "leading dimensions too small"); return PSH_ERR_ARG; }
-    if (d->act_delay_row >= 0) { set_err(c, "fused action delay is not supported yet"); return PSH_ERR_UNSUPPORTED; }
     if (d->policy.n_policies < 1) { set_err(c, "n_policies must be >= 1"); return PSH_ERR_ARG; }
     int rc = check_task(c, d->task, dm[0]);
     if (rc != PSH_OK) return rc;
@@ -846,7 +1019,7 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
     a.init_state = d->init_state; a.ld_init = d->ld_init;
     a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
-    a.task = d->task; a.pol = d->policy;
+    a.task = d->task; a.wrap = d->wrap; a.pol = d->policy;
     a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
     a.obs = d->obs; a.act = d->act; a.rew = d->rew;
     hipStream_t st = (hipStream_t)d->stream;

@@ -34,8 +34,8 @@ def load_library():
                 fn = getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
                 fn.restype = restype
                 fn.argtypes = argtypes
-            if lib.psh_version() != 100:
-                raise EngineError(f'libpysimhip.so has ABI version {lib.psh_version()}, expected 100')
+            if lib.psh_version() != abi.PSH_VERSION:
+                raise EngineError(f'libpysimhip.so has ABI version {lib.psh_version()}, expected {abi.PSH_VERSION}')
             _lib = lib
     return _lib
 
@@ -93,12 +93,14 @@ class Engine:
 
     # -- fused rollouts
     def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *,
-                flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, record=False, act_delay_row=-1,
+                flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, record=False, wrap=None,
                 final_state=True, out=None):
         """ N fused rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]
         (device tensors, fp64).  Returns a dict of device tensors: ret [N], length [N], status [N], final_state [S, N]
-        and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N]. """
+        and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N].  `wrap` (a WrapSpec) fuses environment
+        wrappers into the step loop; with an ObsPartialWrapper in it O is the number of kept observations. """
         S, O, A, P, _ = abi.ENV_DIMS[env_kind]
+        O_rec = O if wrap is None else wrap.obs_dim(O)
         init_state, domain_param = self.f64(init_state), self.f64(domain_param)
         params = self.f64(params)
         if params.dim() == 1:
@@ -113,14 +115,15 @@ class Engine:
             if final_state:
                 out['final_state'] = torch.empty((S, N), dtype=torch.float64, device=dev)
             if record:
-                out['obs'] = torch.full((T + 1, O, N), float('nan'), dtype=torch.float64, device=dev)
+                out['obs'] = torch.full((T + 1, O_rec, N), float('nan'), dtype=torch.float64, device=dev)
                 out['act'] = torch.full((T, A, N), float('nan'), dtype=torch.float64, device=dev)
                 out['rew'] = torch.full((T, N), float('nan'), dtype=torch.float64, device=dev)
         d = abi.PshRolloutDesc()
         d.env_kind, d.n_envs, d.max_steps, d.flags, d.dt = env_kind, N, T, flags, float(dt)
         d.init_state, d.init_dim, d.ld_init = _ptr(init_state), init_state.shape[0], N
         d.domain_param, d.dp_index, d.ld_dp = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1]
-        d.act_delay_row = act_delay_row
+        if wrap is not None:
+            d.wrap = wrap.to_c(O, A)
         d.task = task_c
         d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index))
         d.ret, d.length, d.status = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status'])

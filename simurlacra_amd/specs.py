@@ -122,3 +122,62 @@ class PolicySpec:
         p.params = params_ptr
         p.policy_index = index_ptr
         return p
+
+
+WRAP_IDS = dict(act_norm=abi.WRAP_ACT_NORM, act_delay=abi.WRAP_ACT_DELAY, act_noise=abi.WRAP_ACT_NOISE,
+                obs_noise=abi.WRAP_OBS_NOISE, obs_norm=abi.WRAP_OBS_NORM, obs_partial=abi.WRAP_OBS_PARTIAL)
+
+
+@dataclass
+class WrapSpec:
+    """ The environment wrappers fused into a rollout (Pyrado/pyrado/environment_wrappers/{action_normalization,
+    action_delay,action_noise,observation_noise,observation_normalization,observation_partial}.py), OUTERMOST first.
+    Vectors are indexed by the simulation's own observation / action index. """
+    ops: Sequence[str] = field(default_factory=list)
+    act_delay: int = 0
+    act_delay_row: int = -1                 # row of the domain-parameter table holding per-env delays
+    obs_keep: Optional[Sequence[bool]] = None
+    noise_seed: int = 0
+    env_offset: int = 0
+    act_noise_mean: Optional[Sequence[float]] = None
+    act_noise_std: Optional[Sequence[float]] = None
+    obs_noise_mean: Optional[Sequence[float]] = None
+    obs_noise_std: Optional[Sequence[float]] = None
+    obs_lo: Optional[Sequence[float]] = None   # NaN entries: the simulation's own bound
+    obs_hi: Optional[Sequence[float]] = None
+
+    def obs_dim(self, O: int) -> int:
+        if 'obs_partial' in self.ops:
+            return int(np.count_nonzero(np.asarray(self.obs_keep, dtype=bool)))
+        return O
+
+    def to_c(self, O: int, A: int) -> abi.PshWrappers:
+        w = abi.PshWrappers()
+        ops = list(self.ops)
+        if len(ops) > abi.PSH_MAX_WRAP or len(set(ops)) != len(ops):
+            raise ValueError('each wrapper kind can be fused once')
+        w.n_ops = len(ops)
+        for i, name in enumerate(ops):
+            w.ops[i] = WRAP_IDS[name]
+        if not 0 <= int(self.act_delay) <= abi.PSH_MAX_DELAY:
+            raise ValueError(f'act_delay must be within 0..{abi.PSH_MAX_DELAY}')
+        w.act_delay, w.act_delay_row = int(self.act_delay), int(self.act_delay_row)
+        keep = np.ones(O, dtype=bool) if self.obs_keep is None else np.asarray(self.obs_keep, dtype=bool).reshape(-1)
+        if keep.size != O:
+            raise ValueError(f'obs_keep has {keep.size} entries, the simulation observes {O}')
+        w.obs_keep_mask = int(sum(1 << r for r in range(O) if keep[r]))
+        w.noise_seed, w.env_offset = int(self.noise_seed) & (2**64 - 1), int(self.env_offset)
+
+        def fill(dst, src, n, default):
+            v = np.full(n, default, dtype=np.float64) if src is None else np.asarray(src, dtype=np.float64).reshape(-1)
+            if v.size != n:
+                raise ValueError(f'expected {n} entries, got {v.size}')
+            for i in range(n):
+                dst[i] = v[i]
+        fill(w.act_noise_mean, self.act_noise_mean, A, 0.)
+        fill(w.act_noise_std, self.act_noise_std, A, 0.)
+        fill(w.obs_noise_mean, self.obs_noise_mean, O, 0.)
+        fill(w.obs_noise_std, self.obs_noise_std, O, 0.)
+        fill(w.obs_lo, self.obs_lo, O, np.nan)
+        fill(w.obs_hi, self.obs_hi, O, np.nan)
+        return w

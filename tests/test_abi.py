@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(abi.PSH_SYMBOLS), declared ^ set(abi.PSH_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.psh_version() == 100
+    assert lib.psh_version() == abi.PSH_VERSION
 
 
 def test_env_dims_match_the_python_table():
@@ -48,7 +48,8 @@ def test_constants_of_the_ctypes_mirror_match_the_header():
 def test_struct_layouts_match_the_c_compiler(tmp_path):
     """ sizeof/offsetof of every ABI struct as gcc lays them out vs the ctypes mirror """
     import subprocess
-    structs = {'psh_task': abi.PshTask, 'psh_policy': abi.PshPolicy, 'psh_rollout_desc': abi.PshRolloutDesc,
+    structs = {'psh_task': abi.PshTask, 'psh_policy': abi.PshPolicy, 'psh_wrappers': abi.PshWrappers,
+               'psh_rollout_desc': abi.PshRolloutDesc,
                'psh_step_desc': abi.PshStepDesc, 'psh_distr': abi.PshDistr, 'psh_rand_desc': abi.PshRandDesc,
                'psh_init_desc': abi.PshInitDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pysimhip.h"', 'int main(void){']

@@ -76,6 +76,41 @@ def test_fnn_nan_parameter_is_flagged(eng, orc, hidden):
     assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+@pytest.mark.parametrize('kind,wrap', cases.WRAP_CASES, ids=lambda v: '-'.join(v.ops) if hasattr(v, 'ops') else str(v))
+def test_rollout_with_fused_wrappers(eng, orc, kind, wrap, policy):
+    """ ActNorm / ActDelay (fixed and per-env randomized) / Gaussian action and observation noise / ObsNorm /
+    ObsPartial fused into the step loop, in the nesting order of the Python objects. """
+    import copy
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    n, T = 300, 40
+    wrap = copy.deepcopy(wrap)
+    wrap.env_offset = 12345678901
+    kw = dict(obs_dim=wrap.obs_dim(O), scale=0.3)
+    if policy == 'fnn':
+        kw['hidden'] = (32, 32)
+    case = cases.make_case(kind, n, seed=55 + kind, policy=policy, **kw)
+    dp = case['dp']
+    if wrap.act_delay_row >= 0:
+        dp = np.vstack([dp, np.random.default_rng(3).integers(0, 6, n).astype(float)[None, :]])
+    case = dict(case, dp=dp)
+    _compare_rollouts(eng, orc, case, T=T, wrap=wrap)
+
+
+def test_fused_delay_with_lane_refill(eng, orc):
+    """ More envs than resident lanes and short episodes: lanes take over new envs, whose delay queues must start
+    empty although the ring-buffer memory is reused. """
+    kind = abi.ENV_BOB
+    n = 300000
+    case = cases.make_case(kind, n, seed=4, policy='linear', scale=2.0)
+    wrap = cases.WrapSpec(ops=['act_delay', 'act_norm'], act_delay_row=8)
+    dp = np.vstack([case['dp'], np.random.default_rng(1).integers(0, 9, n).astype(float)[None, :]])
+    ref = orc.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], case['params'], case['init'], dp, wrap=wrap)
+    out = eng.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], case['params'], case['init'], dp, wrap=wrap)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+
+
 @pytest.mark.parametrize('kind', cases.KINDS)
 def test_reset_step(eng, orc, kind):
     import torch
