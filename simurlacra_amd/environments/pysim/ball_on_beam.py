@@ -18,7 +18,7 @@ class BallOnBeamSim(SimPyEnv):
         l_beam, g = self._domain_param['l_beam'], self._domain_param['g']
         max_state = np.array([l_beam/2., np.pi/4., 10., np.pi])
         max_act = np.array([l_beam/2.*g*3.])
-        labels = ['x', 'alpha', 'x_dot', 'alpha_dot']
+        labels = ['$x$', r'$\alpha$', r'$\dot{x}$', r'$\dot{\alpha}$']
         self._state_space = BoxSpace(-max_state, max_state, labels=labels)
         self._obs_space = self._state_space
         self._init_space = CompoundSpace([
@@ -27,7 +27,7 @@ class BallOnBeamSim(SimPyEnv):
             BoxSpace(np.array([0.7*l_beam/2., -5/180.*np.pi, -0.02*max_state[2], -0.02*max_state[3]]),
                      np.array([0.8*l_beam/2., +5/180.*np.pi, +0.02*max_state[2], +0.02*max_state[3]]), labels=labels),
         ])
-        self._act_space = BoxSpace(-max_act, max_act, labels=['tau'])
+        self._act_space = BoxSpace(-max_act, max_act, labels=[r'$\tau$'])
 
     def _create_task(self, task_args: dict):
         state_des = task_args.get('state_des', np.zeros(4))

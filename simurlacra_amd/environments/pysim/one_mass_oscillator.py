@@ -21,10 +21,10 @@ class OneMassOscillatorSim(SimPyEnv):
         min_init = np.array([-0.75*max_state[0], -0.01*max_state[1]])
         max_init = np.array([-0.65*max_state[0], +0.01*max_state[1]])
         max_act = np.array([max_state[0]*k])
-        self._state_space = BoxSpace(-max_state, max_state, labels=['x', 'x_dot'])
+        self._state_space = BoxSpace(-max_state, max_state, labels=['$x$', r'$\dot{x}$'])
         self._obs_space = self._state_space
-        self._init_space = BoxSpace(min_init, max_init, labels=['x', 'x_dot'])
-        self._act_space = BoxSpace(-max_act, max_act, labels=['F'])
+        self._init_space = BoxSpace(min_init, max_init, labels=['$x$', r'$\dot{x}$'])
+        self._act_space = BoxSpace(-max_act, max_act, labels=['$F$'])
 
     def _create_task(self, task_args: dict):
         state_des = task_args.get('state_des', np.zeros(2))

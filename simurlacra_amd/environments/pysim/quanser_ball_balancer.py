@@ -46,11 +46,11 @@ class QBallBalancerSim(SimPyEnv):
         min_init = np.array([0.75*l_plate/2, -np.pi, -0.05*max_state[6], -0.05*max_state[7]])
         max_init = np.array([0.8*l_plate/2, np.pi, 0.05*max_state[6], 0.05*max_state[7]])
         max_act = np.array([3.0, 3.0])
-        self._state_space = BoxSpace(-max_state, max_state, labels=['theta_x', 'theta_y', 'x', 'y', 'theta_x_dot',
-                                                                   'theta_y_dot', 'x_dot', 'y_dot'])
+        self._state_space = BoxSpace(-max_state, max_state, labels=[r'$\theta_x$', r'$\theta_y$', '$x$', '$y$', r'$\dot{\theta}_x$',
+                                                                   r'$\dot{\theta}_y$', r'$\dot{x}$', r'$\dot{y}$'])
         self._obs_space = self._state_space.copy()
-        self._init_space = Polar2DPosVelSpace(min_init, max_init, labels=['r', 'phi', 'x_dot', 'y_dot'])
-        self._act_space = BoxSpace(-max_act, max_act, labels=['V_x', 'V_y'])
+        self._init_space = Polar2DPosVelSpace(min_init, max_init, labels=['$r$', r'$\phi$', r'$\dot{x}$', r'$\dot{y}$'])
+        self._act_space = BoxSpace(-max_act, max_act, labels=['$V_x$', '$V_y$'])
 
     def _create_task(self, task_args: dict):
         state_des = task_args.get('state_des', np.zeros(8))

@@ -24,8 +24,8 @@ class QCartPoleSim(SimPyEnv):
     def _create_spaces(self):
         l_rail = self._domain_param['l_rail']
         max_obs = np.array([l_rail/2., 1., 1., np.inf, np.inf])
-        self._obs_space = BoxSpace(-max_obs, max_obs, labels=['x', 'sin_theta', 'cos_theta', 'x_dot', 'theta_dot'])
-        self._act_space = BoxSpace(-np.array([8.]), np.array([8.]), labels=['V'])
+        self._obs_space = BoxSpace(-max_obs, max_obs, labels=['$x$', r'$\sin(\theta)$', r'$\cos(\theta)$', r'$\dot{x}$', r'$\dot{\theta}$'])
+        self._act_space = BoxSpace(-np.array([8.]), np.array([8.]), labels=['$V$'])
 
     def observe(self, state):
         return np.array([state[0], np.sin(state[1]), np.cos(state[1]), state[2], state[3]])
@@ -51,7 +51,7 @@ class QCartPoleStabSim(QCartPoleSim):
         max_state = np.array([+l_rail/2. - self.x_buffer, np.pi + self.stab_thold, +l_rail, +2*np.pi])
         max_init = np.array([+0.05, np.pi + self.max_init_th_offset, +0.05, +8/180*np.pi])
         min_init = np.array([-0.05, np.pi - self.max_init_th_offset, -0.05, -8/180*np.pi])
-        labels = ['x', 'theta', 'x_dot', 'theta_dot']
+        labels = ['$x$', r'$\theta$', r'$\dot{x}$', r'$\dot{\theta}$']
         self._state_space = BoxSpace(min_state, max_state, labels=labels)
         self._init_space = BoxSpace(min_init, max_init, labels=labels)
 
@@ -73,7 +73,7 @@ class QCartPoleSwingUpSim(QCartPoleSim):
         max_state = np.array([+l_rail/2. - self.x_buffer, +4*np.pi, np.inf, np.inf])
         min_state = np.array([-l_rail/2. + self.x_buffer, -4*np.pi, -np.inf, -np.inf])
         max_init = np.array([0.03, 1/180.*np.pi, 0.005, 2/180.*np.pi])
-        labels = ['x', 'theta', 'x_dot', 'theta_dot']
+        labels = ['$x$', r'$\theta$', r'$\dot{x}$', r'$\dot{\theta}$']
         self._state_space = BoxSpace(min_state, max_state, labels=labels)
         self._init_space = BoxSpace(-max_init, max_init, labels=labels)
 

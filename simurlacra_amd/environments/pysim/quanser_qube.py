@@ -20,11 +20,11 @@ class QQubeSim(SimPyEnv):
         max_state = np.array([115./180*np.pi, 4*np.pi, 20*np.pi, 20*np.pi])
         max_obs = np.array([1., 1., 1., 1., np.inf, np.inf])
         max_init_state = np.array([2., 1., 0.5, 0.5])/180*np.pi
-        self._state_space = BoxSpace(-max_state, max_state, labels=['theta', 'alpha', 'theta_dot', 'alpha_dot'])
-        self._obs_space = BoxSpace(-max_obs, max_obs, labels=['sin_theta', 'cos_theta', 'sin_alpha', 'cos_alpha',
-                                                              'theta_dot', 'alpha_dot'])
-        self._init_space = BoxSpace(-max_init_state, max_init_state, labels=['theta', 'alpha', 'theta_dot', 'alpha_dot'])
-        self._act_space = BoxSpace(-max_volt, max_volt, labels=['V'])
+        self._state_space = BoxSpace(-max_state, max_state, labels=[r'$\theta$', r'$\alpha$', r'$\dot{\theta}$', r'$\dot{\alpha}$'])
+        self._obs_space = BoxSpace(-max_obs, max_obs, labels=[r'$\sin\theta$', r'$\cos\theta$', r'$\sin\alpha$', r'$\cos\alpha$',
+                                                              r'$\dot{\theta}$', r'$\dot{\alpha}$'])
+        self._init_space = BoxSpace(-max_init_state, max_init_state, labels=[r'$\theta$', r'$\alpha$', r'$\dot{\theta}$', r'$\dot{\alpha}$'])
+        self._act_space = BoxSpace(-max_volt, max_volt, labels=['$V$'])
 
     def _create_task(self, task_args: dict):
         state_des = task_args.get('state_des', np.array([0., np.pi, 0., 0.]))

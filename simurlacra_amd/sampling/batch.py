@@ -13,14 +13,23 @@ import torch
 from .. import _abi as abi, inf
 from ..envdefs import DP_NAMES
 from ..environment_wrappers.action_delay import ActDelayWrapper
+from ..environment_wrappers.action_noise import GaussianActNoiseWrapper
 from ..environment_wrappers.action_normalization import ActNormWrapper
 from ..environment_wrappers.base import EnvWrapper
+from ..environment_wrappers.observation_noise import GaussianObsNoiseWrapper
+from ..environment_wrappers.observation_normalization import ObsNormWrapper
+from ..environment_wrappers.observation_partial import ObsPartialWrapper
 from ..environment_wrappers.domain_randomization import (DomainRandWrapper, DomainRandWrapperBuffer,
                                                           DomainRandWrapperLive, MetaDomainRandWrapper)
 from ..environment_wrappers.utils import all_envs, inner_env
 from ..environments.pysim.base import SimPyEnv
+from ..specs import WrapSpec
 from ..utils.exceptions import ValueErr
 from .step_sequence import StepSequence
+
+
+_WRAP_OPS = {ActNormWrapper: 'act_norm', ActDelayWrapper: 'act_delay', GaussianActNoiseWrapper: 'act_noise',
+             GaussianObsNoiseWrapper: 'obs_noise', ObsNormWrapper: 'obs_norm', ObsPartialWrapper: 'obs_partial'}
 
 
 class EnvPlan:
@@ -35,25 +44,80 @@ class EnvPlan:
         self.kind = self.sim.kind
         self.S, self.O, self.A, self.P, self.I = abi.ENV_DIMS[self.kind]
         self.dr_wrapper = None       # outermost DomainRandWrapperLive/Buffer (Meta wrappers forward to it)
-        self.act_wrappers = []       # action wrappers from the outside in
+        self.wrappers = []           # action / observation wrappers from the outside in: (op name, wrapper)
         for e in all_envs(env):
             if isinstance(e, MetaDomainRandWrapper):
                 continue
             if isinstance(e, DomainRandWrapper):
                 if self.dr_wrapper is None:
                     self.dr_wrapper = e
-            elif isinstance(e, (ActNormWrapper, ActDelayWrapper)):
-                self.act_wrappers.append(e)
+            elif type(e) in _WRAP_OPS:
+                op = _WRAP_OPS[type(e)]
+                if any(op == o for o, _ in self.wrappers):
+                    raise NotImplementedError(f'two {type(e).__name__} in one environment chain are not supported by '
+                                              f'the batched rollout engine')
+                self.wrappers.append((op, e))
             elif isinstance(e, EnvWrapper):
                 raise NotImplementedError(f'{type(e).__name__} is not supported by the batched rollout engine')
         self.names = DP_NAMES[self.kind]
+        self.delay_wrapper = next((w for op, w in self.wrappers if op == 'act_delay'), None)
+        # the delay travels as one more row of the domain-parameter table (it is the domain parameter 'act_delay')
+        self.extra_rows = ['act_delay'] if self.delay_wrapper is not None else []
 
     @property
-    def fusable_env(self) -> bool:
-        return not self.act_wrappers
+    def obs_dim(self) -> int:
+        """ Entries of the observation as the policy sees it. """
+        return int(self.env.obs_space.flat_dim)
 
     def flags(self, stop_on_done=True) -> int:
         return self.sim.engine_flags() | (abi.F_STOP_ON_DONE if stop_on_done else 0)
+
+    def wrap_spec(self, noise_seed: int = 0, env_offset: int = 0):
+        """ The wrapper chain as the kernels take it (vectors indexed by the simulation's observation / action
+        index), or None for a bare simulation. """
+        if not self.wrappers:
+            return None
+        O = self.O
+        spec = WrapSpec(ops=[op for op, _ in self.wrappers], noise_seed=noise_seed, env_offset=env_offset)
+        partial = next((w for op, w in self.wrappers if op == 'obs_partial'), None)
+        keep = np.ones(O, dtype=bool) if partial is None else np.asarray(partial.keep_mask, dtype=bool)
+
+        def to_sim_index(vec, fill):
+            """ a vector over the observation of a wrapper's inner env, which may already be the reduced one """
+            vec = np.asarray(vec, dtype=np.float64).reshape(-1)
+            if vec.size == O:
+                return vec
+            full = np.full(O, fill, dtype=np.float64)
+            full[keep] = vec
+            return full
+        labels = self.sim.obs_space.labels
+        for op, w in self.wrappers:
+            if op == 'act_delay':
+                spec.act_delay, spec.act_delay_row = int(w.delay), self.P
+            elif op == 'act_noise':
+                spec.act_noise_mean, spec.act_noise_std = w._mean, w._std
+            elif op == 'obs_noise':
+                spec.obs_noise_mean, spec.obs_noise_std = to_sim_index(w._mean, 0.), to_sim_index(w._std, 0.)
+            elif op == 'obs_partial':
+                spec.obs_keep = keep
+            elif op == 'obs_norm':
+                lo, hi = np.full(O, np.nan), np.full(O, np.nan)
+                for r, name in enumerate(labels):
+                    if w.explicit_lb and w.explicit_lb.get(name) is not None:
+                        lo[r] = w.explicit_lb[name]
+                    if w.explicit_ub and w.explicit_ub.get(name) is not None:
+                        hi[r] = w.explicit_ub[name]
+                w.obs_space  # raises the reference's ValueErr for an infinite bound that is not overridden
+                spec.obs_lo, spec.obs_hi = lo, hi
+        return spec
+
+    def dp_column(self, d: dict = None) -> np.ndarray:
+        """ One column of the device table: the simulation's parameters (overridden by `d`), then the action delay """
+        col = self.sim.domain_param_column(d)
+        if self.delay_wrapper is not None:
+            delay = int(d['act_delay']) if d is not None and 'act_delay' in d else int(self.delay_wrapper.delay)
+            col = np.append(col, float(delay))
+        return col
 
     def dp_dicts(self, table: np.ndarray, index=None, extra=None):
         """ Domain-parameter dicts (as rollout_info['domain_param'] holds them) for the columns of a table. """
@@ -63,6 +127,8 @@ class EnvPlan:
         for c in cols:
             d = dict(base)
             d.update({k: table[r, c] for r, k in enumerate(self.names)})
+            if self.extra_rows and table.shape[0] > self.P:
+                d['act_delay'] = int(table[self.P, c])
             if extra:
                 d.update(extra)
             out.append(d)
@@ -70,31 +136,34 @@ class EnvPlan:
 
 
 def sample_domain_params(plan: EnvPlan, eng, n: int, seed: int, env_offset: int = 0):
-    """ Domain parameters for n environments as a device table [P, M] plus an index [n] (or None when M == n).
+    """ Domain parameters for n environments as a device table [P (+1), M] plus an index [n] (or None when M == n).
     Live wrapper: drawn on the device from the randomizer's distributions (host torch.distributions only for
     distributions without a device sampler); buffer wrapper: the buffer is the table and the ring index advances by
-    n; no wrapper: the environment's current parameters for every lane. """
+    n; no wrapper: the environment's current parameters for every lane.  With an ActDelayWrapper in the chain the
+    table has one more row, the delay of each column (the domain parameter 'act_delay'). """
     w = plan.dr_wrapper
     nominal = plan.sim.domain_param_column()
+    delay = [float(plan.delay_wrapper.delay)] if plan.delay_wrapper is not None else []
+    column = plan.dp_column
     if w is None:
-        return eng.f64(nominal.reshape(-1, 1)), torch.zeros(n, dtype=torch.int32, device=eng.device)
+        return eng.f64(column().reshape(-1, 1)), torch.zeros(n, dtype=torch.int32, device=eng.device)
     if isinstance(w, DomainRandWrapperBuffer) and w.buffer is not None:
         buf = w.buffer if isinstance(w.buffer, list) else [w.buffer]
-        table = np.stack([plan.sim.domain_param_column(d) for d in buf], axis=1)
+        table = np.stack([column(d) for d in buf], axis=1)
         start = w.ring_idx or 0
         idx = (start + np.arange(n)) % len(buf)
         w._ring_idx = int((start + n) % len(buf))
         return eng.f64(table), eng.i32(idx)
     rand = w.randomizer
     try:
-        distrs = rand.device_table(plan.names)
+        distrs = rand.device_table(plan.names, plan.extra_rows)
     except NotImplementedError:
         rand.randomize(n)
         lst = rand.get_params(-1, format='list', dtype='numpy')
         lst = [lst] if isinstance(lst, dict) else lst
-        return eng.f64(np.stack([plan.sim.domain_param_column({k: float(v) for k, v in d.items() if k in plan.names})
-                                 for d in lst], axis=1)), None
-    return eng.randomize(n, distrs, list(nominal), seed=seed, env_offset=env_offset), None
+        keys = list(plan.names) + plan.extra_rows
+        return eng.f64(np.stack([column({k: float(v) for k, v in d.items() if k in keys}) for d in lst], axis=1)), None
+    return eng.randomize(n, distrs, list(nominal) + delay, seed=seed, env_offset=env_offset), None
 
 
 def sample_init_states(plan: EnvPlan, eng, n: int, dp, dp_index, seed: int, env_offset: int = 0):
@@ -102,9 +171,10 @@ def sample_init_states(plan: EnvPlan, eng, n: int, dp, dp_index, seed: int, env_
 
 
 def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_steps=None, stop_on_done=True,
-              record=True, params=None, policy_index=None):
-    """ N rollouts on the device.  Fused kernel when the policy and the env chain allow it, else a step loop with the
-    policy evaluated by torch on the whole batch.  Returns the dict of device tensors of Engine.rollout. """
+              record=True, params=None, policy_index=None, noise_seed=0, env_offset=0):
+    """ N rollouts on the device.  Fused kernel when the policy allows it (the wrappers of the env chain are fused
+    with it), else a step loop with the policy evaluated by torch on the whole batch.  Returns the dict of device
+    tensors of Engine.rollout. """
     T = plan.env.max_steps if max_steps is None else max_steps
     if T == inf:
         raise ValueErr(msg='batched rollouts need a finite max_steps')
@@ -112,58 +182,115 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
     S, A = plan.S, plan.A
     task_c = plan.sim.task_spec().to_c(S, A)
     spec = policy.fused_spec() if hasattr(policy, 'fused_spec') else None
-    if spec is not None and plan.fusable_env:
+    wrap = plan.wrap_spec(noise_seed, env_offset)
+    if spec is not None:
+        if spec.obs_dim != plan.obs_dim:
+            raise ValueErr(msg=f'the policy takes {spec.obs_dim} observations, the environment yields {plan.obs_dim}')
         if params is None:
             params = policy.param_values.detach().to(torch.float64)
-        return eng.rollout(plan.kind, plan.sim.dt, T, task_c, spec, params, init_state, dp,
-                           flags=plan.flags(stop_on_done), dp_index=dp_index, policy_index=policy_index, record=record)
+        return eng.rollout(plan.kind, plan.sim.dt, T, task_c, spec, params, init_state, dp, flags=plan.flags(stop_on_done),
+                           dp_index=dp_index, policy_index=policy_index, record=record, wrap=wrap)
     if params is not None:
-        raise NotImplementedError('per-environment policy parameters need a fusable policy and environment chain')
-    return _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c)
+        raise NotImplementedError('per-environment policy parameters need a fusable policy')
+    return _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap)
 
 
-def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c):
-    """ rollout() loop (Pyrado/pyrado/sampling/rollout.py:133-254) for N envs at once with an arbitrary torch policy. """
+def _obs_bounds(plan, dp, dp_index, N):
+    """ Per-lane observation bounds of the simulation [O, N] (they can depend on its domain parameters). """
+    cols = dp if dp_index is None else dp[:, dp_index.long()]
+    if cols.shape[1] != N:
+        cols = cols.expand(-1, N)
+    k, dev = plan.kind, cols.device
+    one = torch.ones((1, N), dtype=torch.float64, device=dev)
+    pi = float(np.pi)
+    if k == abi.ENV_QQ:
+        hi = torch.cat([one, one, one, one, one*float('inf'), one*float('inf')])
+    elif k in (abi.ENV_QCP_SU, abi.ENV_QCP_ST):
+        hi = torch.cat([cols[2:3]/2., one, one, one*float('inf'), one*float('inf')])
+    elif k == abi.ENV_QBB:
+        hi = torch.cat([one*pi/4., one*pi/4., cols[3:4]/2., cols[3:4]/2., one*5*pi, one*5*pi, one*0.5, one*0.5])
+    elif k == abi.ENV_BOB:
+        hi = torch.cat([cols[4:5]/2., one*pi/4., one*10., one*pi])
+    else:
+        hi = torch.cat([one, one*10.])
+    return -hi, hi
+
+
+def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap=None):
+    """ rollout() loop (Pyrado/pyrado/sampling/rollout.py:133-254) for N envs at once with an arbitrary torch policy;
+    the wrappers of the chain are applied to the whole batch between policy and psh_step.  Noise comes from torch's
+    generator here (the fused kernels use their own counter-based one). """
     kind, dt, dev = plan.kind, plan.sim.dt, eng.device
     init_state, dp = eng.f64(init_state), eng.f64(dp)
+    dp_index = eng.i32(dp_index)
     N, O, A = init_state.shape[1], plan.O, plan.A
+    ops = [] if wrap is None else list(wrap.ops)
+    Oe = O if wrap is None else wrap.obs_dim(O)
     flags = plan.sim.engine_flags()
     mem = eng.reset(kind, dt, T, task_c, init_state, dp, flags=flags, dp_index=dp_index)
     out = dict(ret=torch.zeros(N, dtype=torch.float64, device=dev), length=torch.zeros(N, dtype=torch.int32, device=dev),
                status=torch.zeros(N, dtype=torch.int32, device=dev))
     if record:
-        out['obs'] = torch.full((T + 1, O, N), float('nan'), dtype=torch.float64, device=dev)
+        out['obs'] = torch.full((T + 1, Oe, N), float('nan'), dtype=torch.float64, device=dev)
         out['act'] = torch.full((T, A, N), float('nan'), dtype=torch.float64, device=dev)
         out['rew'] = torch.full((T, N), float('nan'), dtype=torch.float64, device=dev)
     live = torch.ones(N, dtype=torch.bool, device=dev)
     pol_dev = next((p.device for p in policy.parameters()), torch.device('cpu')) if hasattr(policy, 'parameters') else torch.device('cpu')
-    # action wrappers, outermost first: ActNorm uses the inner env's per-lane bounds, ActDelay a per-lane queue
-    delays, queue = None, None
-    for w in plan.act_wrappers:
-        if isinstance(w, ActDelayWrapper):
-            delays = torch.full((N,), int(w.delay), dtype=torch.int64, device=dev)
-            queue = torch.zeros((int(w.delay) + 1, A, N), dtype=torch.float64, device=dev)
+
+    def vec(v, n):
+        return torch.as_tensor(np.zeros(n) if v is None else np.asarray(v, dtype=np.float64), device=dev).reshape(n, 1)
+    keep = None
+    if 'obs_partial' in ops:
+        keep = torch.as_tensor(np.asarray(wrap.obs_keep, dtype=bool), device=dev)
+    if 'obs_norm' in ops:
+        o_lo, o_hi = _obs_bounds(plan, dp, dp_index, N)
+        lo_ov, hi_ov = vec(wrap.obs_lo, O), vec(wrap.obs_hi, O)
+        o_lo = torch.where(torch.isnan(lo_ov), o_lo, lo_ov)
+        o_hi = torch.where(torch.isnan(hi_ov), o_hi, hi_ov)
+
+    def process_obs(o):  # observation wrappers, innermost first
+        for op in reversed(ops):
+            if op == 'obs_noise':
+                o = o + (torch.randn((O, N), dtype=torch.float64, device=dev)*vec(wrap.obs_noise_std, O)
+                         + vec(wrap.obs_noise_mean, O))
+            elif op == 'obs_norm':
+                o = (o - o_lo)/(o_hi - o_lo)*2 - 1
+        return o if keep is None else o[keep]
+    # ActDelayWrapper with per-lane delays: a history ring of the last PSH_MAX_DELAY + 1 actions
+    delays = hist = None
+    if 'act_delay' in ops:
+        cols = dp if dp_index is None else dp[:, dp_index.long()]
+        delays = (cols[wrap.act_delay_row] if wrap.act_delay_row >= 0 else torch.full((N,), float(wrap.act_delay), device=dev))
+        delays = delays.expand(N).clamp(0, abi.PSH_MAX_DELAY).long()
+        H = int(delays.max().item()) + 1
+        hist = torch.zeros((H, A, N), dtype=torch.float64, device=dev)
+    alias = not ('act_norm' in ops or 'act_noise' in ops)
+    lane = torch.arange(N, device=dev)
     if hasattr(policy, 'reset'):
         policy.reset()
     k = 0
-    obs = mem['obs'].clone()
+    obs = process_obs(mem['obs'].clone())
     while bool(live.any()) and k < T:
         if record:
             out['obs'][k][:, live] = obs[:, live]
         with torch.no_grad():
             act = policy(obs.t().to(pol_dev)).to(dev, torch.float64).reshape(N, A).t().contiguous()
         nan = torch.isnan(act).any(dim=0) | torch.isnan(obs).any(dim=0)
-        rec_act = act.clone()
-        for w in plan.act_wrappers:
-            if isinstance(w, ActNormWrapper):
+        inner = act.clone()
+        for op in ops:  # action wrappers, outermost first
+            if op == 'act_norm':
                 lo, hi = _act_bounds(plan, dp, dp_index, N)
-                act = lo + (act + 1)*(hi - lo)/2
-            elif isinstance(w, ActDelayWrapper) and queue is not None and queue.shape[0] > 1:
-                queue[-1] = act
-                act = queue[0].clone()
-                queue[:-1] = queue[1:].clone()
+                inner = lo + (inner + 1)*(hi - lo)/2
+            elif op == 'act_delay' and hist.shape[0] > 1:
+                hist[k % hist.shape[0]] = inner
+                src = (k - delays) % hist.shape[0]
+                inner = torch.where((k >= delays).unsqueeze(0), hist[src, :, lane].t(), torch.zeros_like(inner))
+            elif op == 'act_noise':
+                inner = inner + (torch.randn((A, N), dtype=torch.float64, device=dev)*vec(wrap.act_noise_std, A)
+                                 + vec(wrap.act_noise_mean, A))
+        inner = inner.contiguous()
         mem_prev = {key: v.clone() for key, v in mem.items()}
-        o, r, d, st = eng.step(kind, dt, T, task_c, mem, act, dp, flags=flags, dp_index=dp_index)
+        o, r, d, st = eng.step(kind, dt, T, task_c, mem, inner, dp, flags=flags, dp_index=dp_index)
         # lanes that were not live keep their memory
         for key in mem:
             sel = ~live
@@ -173,12 +300,17 @@ def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_
                 mem[key][sel] = mem_prev[key][sel]
         stepped = live & ~nan
         if record:
-            out['act'][k][:, stepped] = (act if not plan.act_wrappers else rec_act)[:, stepped]
+            out['act'][k][:, stepped] = act[:, stepped]
+            if alias:
+                # the simulation wrote (QBB dead zone) into the array it received: the action recorded `delay` steps ago
+                back = (k - delays) if delays is not None else torch.full((N,), k, device=dev)
+                sel = stepped & (back >= 0)
+                out['act'][back[sel], :, lane[sel]] = inner[:, sel].t()
             out['rew'][k][stepped] = r[stepped]
         out['ret'] += torch.where(stepped, r, torch.zeros_like(r))
         out['length'] += stepped.to(torch.int32)
         out['status'] |= torch.where(stepped, st, torch.zeros_like(st)) | ((live & nan).to(torch.int32)*abi.ST_NAN)
-        obs = torch.where(stepped.unsqueeze(0), o, obs)
+        obs = torch.where(stepped.unsqueeze(0), process_obs(o), obs)
         done = d.bool() & stepped
         live = stepped & ~(done & stop_on_done) & ~((st & abi.ST_NAN) != 0)
         k += 1

@@ -14,13 +14,13 @@ def _evaluate(env, policy, dp_dicts, init_states, record=True):
     eng = get_engine()
     plan = EnvPlan(remove_all_dr_wrappers(env))
     n = len(dp_dicts)
-    table = np.stack([plan.sim.domain_param_column(d or {}) for d in dp_dicts], axis=1)
+    table = np.stack([plan.dp_column(d or {}) for d in dp_dicts], axis=1)
     dp = eng.f64(table)
     if init_states is None or any(s is None for s in init_states):
         init = eng.sample_init(plan.kind, n, dp, seed=0)
     else:
         init = eng.f64(np.stack([np.asarray(s, dtype=np.float64) for s in init_states], axis=1))
-    out = run_batch(plan, eng, policy, init, dp, None, record=record)
+    out = run_batch(plan, eng, policy, init, dp, None, record=record, noise_seed=int(np.random.randint(0, 2**31 - 1)))
     batch = RolloutBatch(plan, out, dp)
     batch.check()
     return batch

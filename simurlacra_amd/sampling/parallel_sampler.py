@@ -55,7 +55,8 @@ class ParallelSampler(SamplerBase):
         key = self.seed + 7919*self._calls
         dp, dp_index = sample_domain_params(plan, eng, m, seed=key, env_offset=global_offset + start)
         init = sample_init_states(plan, eng, m, dp, dp_index, seed=key, env_offset=global_offset + start)
-        out = run_batch(plan, eng, self.policy, init, dp, dp_index, record=self.record_trajectories)
+        out = run_batch(plan, eng, self.policy, init, dp, dp_index, record=self.record_trajectories, noise_seed=key,
+                        env_offset=global_offset + start)
         return RolloutBatch(plan, out, dp, dp_index)
 
     def sample(self) -> RolloutBatch:

@@ -13,6 +13,7 @@ import torch as to
 from .. import inf
 from ..environment_wrappers.domain_randomization import (DomainRandWrapperBuffer, DomainRandWrapperLive,
                                                           MetaDomainRandWrapper)
+from ..environment_wrappers.base import EnvWrapper
 from ..environment_wrappers.utils import all_envs, inner_env
 from ..environments.base import Env
 from ..environments.sim_base import SimEnv
@@ -33,7 +34,7 @@ def _fused_plan(env, policy, **conds):
         plan = EnvPlan(env)
     except NotImplementedError:
         return None
-    return plan if plan.fusable_env else None
+    return plan
 
 
 def _reset_host_side(env, init_state, domain_param):
@@ -55,6 +56,9 @@ def _reset_host_side(env, init_state, domain_param):
     sim = inner_env(env)
     sim._curr_step = 0
     if domain_param is not None:
+        for e in all_envs(env):  # EnvWrapper.reset: every wrapper takes its own entries (e.g. 'act_delay')
+            if isinstance(e, EnvWrapper):
+                e._load_domain_param(domain_param)
         sim.domain_param = domain_param
     if init_state is None:
         init_state = sim.init_space.sample_uniform()
@@ -100,8 +104,11 @@ def _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close
         policy.eval() if eval else policy.train()
     eng = get_engine()
     sim = plan.sim
-    dp = eng.f64(sim.domain_param_column().reshape(-1, 1))
-    out = run_batch(plan, eng, policy, eng.f64(init_state.reshape(-1, 1)), dp, stop_on_done=stop_on_done, record=True)
+    dp = eng.f64(plan.dp_column().reshape(-1, 1))
+    # the noise wrappers of the reference draw from NumPy's global generator: take this rollout's key from it
+    noise_seed = int(np.random.randint(0, 2**31 - 1)) if plan.wrappers else 0
+    out = run_batch(plan, eng, policy, eng.f64(init_state.reshape(-1, 1)), dp, stop_on_done=stop_on_done, record=True,
+                    noise_seed=noise_seed)
     batch = RolloutBatch(plan, out, dp)
     batch.check()
     ro = batch[0]

@@ -10,7 +10,9 @@ import torch as to
 import simurlacra_amd as pyrado
 from simurlacra_amd import _abi as abi
 from simurlacra_amd.domain_randomization import get_default_randomizer
-from simurlacra_amd.environment_wrappers import (ActNormWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive)
+from simurlacra_amd.environment_wrappers import (ActDelayWrapper, ActNormWrapper, DomainRandWrapperBuffer,
+                                                 DomainRandWrapperLive, GaussianActNoiseWrapper, GaussianObsNoiseWrapper,
+                                                 ObsNormWrapper, ObsPartialWrapper)
 from simurlacra_amd.environments import (BallOnBeamSim, OneMassOscillatorSim, QBallBalancerSim, QCartPoleStabSim,
                                          QCartPoleSwingUpSim, QQubeSim)
 from simurlacra_amd.policies import (DummyPolicy, FeatureStack, FNNPolicy, IdlePolicy, LinearPolicy, const_feat,
@@ -197,6 +199,84 @@ def test_parallel_sampler_with_a_non_fusable_policy_and_act_norm():
     ref = _rollout_stepwise(env, pol, True, dict(init_state=ro.observations[0].copy()), RenderMode(), 1, None, False,
                             False, False, True)
     assert len(ref) == len(ro) and cases.rel_err(ro.rewards, ref.rewards) <= TOL
+
+
+def test_rollout_with_deterministic_wrappers_fused_equals_stepwise():
+    """ ObsPartial(ActDelay(ActNorm(ObsNorm(sim)))): rollout() through the fused kernel and through the reference's
+    env.reset()/env.step() loop over the wrapper objects agree, incl. the reported spaces. """
+    def chain():
+        env = ENVS['bob'](60)
+        env = ObsNormWrapper(env)
+        env = ActNormWrapper(env)
+        env = ActDelayWrapper(env, delay=3)
+        return ObsPartialWrapper(env, idcs=[r'$\dot{x}$'])
+    env = chain()
+    assert env.obs_space.flat_dim == 3 and np.all(env.act_space.bound_up == 1.)
+    pol = LinearPolicy(env.spec, FeatureStack([const_feat, identity_feat]))
+    pol.param_values = 0.3*to.randn(pol.num_param, dtype=to.float64, generator=to.Generator().manual_seed(1))
+    init = np.array([0.2, 0.05, 0., 0.])
+    ro = rollout(env, pol, eval=True, reset_kwargs=dict(init_state=init.copy()))
+    ref = _rollout_stepwise(chain(), pol, True, dict(init_state=init.copy()), RenderMode(), 1, None, False, False, False, True)
+    assert len(ro) == len(ref) and ro.observations.shape == ref.observations.shape == (len(ro) + 1, 3)
+    assert cases.rel_err(ro.observations, ref.observations) <= TOL
+    assert cases.rel_err(ro.actions, ref.actions) <= TOL and cases.rel_err(ro.rewards, ref.rewards) <= TOL
+    assert ro.rollout_info['domain_param']['act_delay'] == 3
+
+
+def test_sampler_with_the_qbb_wrapper_stack_and_randomized_delay():
+    """ The chain of Pyrado/scripts/training/qbb_spota_hc.py:29-38 (observation noise, normalised actions, action delay
+    drawn per rollout as the domain parameter 'act_delay') runs fused; each rollout reproduces in the NumPy oracle from
+    its recorded domain parameters when the noise is switched off, and the noise has the requested spread. """
+    from oracle import pysim_oracle_np as onp
+    from simurlacra_amd.domain_randomization import UniformDomainParam
+
+    def chain(noise_std):
+        env = ENVS['qbb'](40)
+        env = GaussianObsNoiseWrapper(env, noise_std=noise_std)
+        env = ActNormWrapper(env)
+        env = ActDelayWrapper(env)
+        randomizer = get_default_randomizer(env)
+        randomizer.add_domain_params(UniformDomainParam(name='act_delay', mean=5, halfspan=5, clip_lo=0, roundint=True))
+        return DomainRandWrapperLive(env, randomizer)
+    env = chain([0.]*8)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat]))
+    pol.param_values = 0.2*to.randn(pol.num_param, dtype=to.float64, generator=to.Generator().manual_seed(2))
+    ros = ParallelSampler(env, pol, 1, min_rollouts=64, seed=4).sample()
+    delays = [ro.rollout_info['domain_param']['act_delay'] for ro in ros]
+    assert min(delays) >= 0 and max(delays) <= 10 and len(set(delays)) > 3 and all(isinstance(d, int) for d in delays)
+    W = pol.param_values.detach().numpy().reshape(2, -1)
+    keys = list(onp.nominal('qbb').keys())
+    for ro in list(ros)[:12]:
+        dp = {k: float(v) for k, v in ro.rollout_info['domain_param'].items() if k in keys}
+        dp['act_delay'] = ro.rollout_info['domain_param']['act_delay']
+        np_env = onp.NpActDelay(onp.NpActNorm(onp.NpEnv('qbb', 0.01, 40)))
+        ref = onp.rollout_np(np_env, onp.LinearPolicyNp(['identity'], W), ro.observations[0].copy(), dp)
+        assert ref['length'] == len(ro)
+        assert cases.rel_err(ro.actions, ref['actions']) <= TOL and cases.rel_err(ro.rewards, ref['rewards']) <= TOL
+    # with noise: same seeds give the same rollouts, observations scatter around the noise-free ones
+    std = np.array([0.01, 0.01, 0.002, 0.002, 0.1, 0.1, 0.02, 0.02])
+    noisy = ParallelSampler(chain(std), pol, 1, min_rollouts=64, seed=4).sample()
+    again = ParallelSampler(chain(std), pol, 1, min_rollouts=64, seed=4).sample()
+    np.testing.assert_array_equal(noisy.undiscounted_returns(), again.undiscounted_returns())
+    first = np.stack([n.observations[0] - c.observations[0] for n, c in zip(noisy, ros)])   # same init states, pure noise
+    assert np.all(np.abs(first.std(axis=0)/std - 1) < 0.35) and np.all(np.abs(first.mean(axis=0)) < 0.5*std)
+
+
+def test_non_fusable_policy_with_wrappers_matches_the_fused_path():
+    """ the batched reset/step loop applies the same wrapper chain as the fused kernel (deterministic wrappers) """
+    def chain():
+        return ActDelayWrapper(ActNormWrapper(ObsNormWrapper(ENVS['omo'](30))), delay=2)
+    fus = LinearPolicy(chain().spec, FeatureStack([identity_feat]))
+    fus.param_values = to.tensor([0.4, -0.3], dtype=to.float64)
+
+    class Opaque(to.nn.Module):                      # same function, but nothing the kernels can fuse
+        def forward(self, obs):
+            return obs.to(to.float64) @ fus.param_values.reshape(1, 2).t()
+    a = ParallelSampler(chain(), fus, 1, min_rollouts=16, seed=9).sample()
+    b = ParallelSampler(chain(), Opaque(), 1, min_rollouts=16, seed=9).sample()
+    np.testing.assert_array_equal(a.lengths, b.lengths)
+    assert cases.rel_err(a.undiscounted_returns(), b.undiscounted_returns()) <= TOL
+    assert cases.rel_err(a[3].actions, b[3].actions) <= TOL and cases.rel_err(a[3].observations, b[3].observations) <= TOL
 
 
 def test_param_expl_sampler():

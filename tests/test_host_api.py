@@ -12,6 +12,8 @@ from simurlacra_amd import _abi as abi
 from simurlacra_amd.domain_randomization import (BernoulliDomainParam, DomainRandomizer, MultivariateNormalDomainParam,
                                                  NormalDomainParam, UniformDomainParam, get_default_randomizer,
                                                  get_default_randomizer_qbb, get_zero_var_randomizer)
+from simurlacra_amd.environment_wrappers import (GaussianActNoiseWrapper, GaussianObsNoiseWrapper, ObsNormWrapper,
+                                                 ObsPartialWrapper)
 from simurlacra_amd.environment_wrappers import (ActDelayWrapper, ActNormWrapper, DomainRandWrapperBuffer,
                                                  DomainRandWrapperLive, MetaDomainRandWrapper, inner_env,
                                                  remove_all_dr_wrappers, typed_env)
@@ -290,6 +292,69 @@ def test_act_norm():
     for act, exp in (([0, 0, 0], [0, 1, 0.5]), ([1, 1, 1], [2, 3, 1]), ([-1, -1, -1], [-2, -1, 0])):
         uut.step(np.array(act))
         assert mockenv.last_act == exp
+
+
+def test_obs_wrappers_and_noise_wrappers():
+    """ ObsNormWrapper / ObsPartialWrapper / Gaussian noise wrappers as Pyrado/pyrado/environment_wrappers/
+    {observation_normalization.py:73-106, observation_partial.py:10-47, observation_noise.py, action_noise.py} define them """
+    space = BoxSpace([-2., -1., -np.inf], [2., 3., np.inf], labels=['a', 'b', 'c'])
+    mockenv = MockEnv(obs_space=space, act_space=BoxSpace(-1, 1, shape=(2,)))
+    with pytest.raises(pyrado.ValueErr):
+        ObsNormWrapper(mockenv).obs_space                                   # infinite bound, not overridden
+    with pytest.raises(pyrado.ValueErr):
+        ObsNormWrapper(mockenv, explicit_lb={'a': -4.})._process_obs(np.zeros(3))   # override dict given, 'c' still infinite
+    norm = ObsNormWrapper(mockenv, explicit_lb={'c': -10.}, explicit_ub={'c': 10., 'a': 4.})
+    np.testing.assert_allclose(norm._process_obs(np.array([1., 1., 5.])), [0., 0., 0.5])
+    lo, hi = norm.obs_space.bounds
+    # the reported space keeps the original (here infinite) extent of an overridden entry, in normalised units
+    np.testing.assert_allclose(lo, [-1, -1, -np.inf]); np.testing.assert_allclose(hi, [1/3, 1, np.inf])
+    part = ObsPartialWrapper(mockenv, idcs=['b'])
+    assert list(part.obs_space.labels) == ['a', 'c'] and list(part._process_obs(np.array([1., 2., 3.]))) == [1., 3.]
+    part = ObsPartialWrapper(mockenv, mask=[0, 1, 1], keep_selected=True)
+    assert list(part._process_obs(np.array([1., 2., 3.]))) == [2., 3.] and part.obs_space.flat_dim == 2
+    with pytest.raises(pyrado.ShapeErr):
+        ObsPartialWrapper(mockenv, mask=[0, 1])
+    on = GaussianObsNoiseWrapper(mockenv, noise_std=[0., 0., 0.], noise_mean=[1., 2., 3.])
+    np.testing.assert_allclose(on._process_obs(np.zeros(3)), [1., 2., 3.])
+    on.domain_param = dict(obs_noise_mean=[0., 0., 1.])
+    np.testing.assert_allclose(on._process_obs(np.zeros(3)), [0., 0., 1.])
+    assert 'obs_noise_std' in on.domain_param
+    an = GaussianActNoiseWrapper(mockenv, noise_mean=[0.5, -0.5])
+    an.step(np.array([1., 1.])); assert mockenv.last_act == [1.5, 0.5]
+    an.domain_param = dict(act_noise_mean=[9., 9.])      # the reference stores these where _process_act never looks
+    an.step(np.array([1., 1.])); assert mockenv.last_act == [1.5, 0.5]
+    with pytest.raises(pyrado.ShapeErr):
+        GaussianActNoiseWrapper(mockenv, noise_std=[1.])
+
+
+def test_env_plan_translates_the_wrapper_chain():
+    """ the chain of scripts/training/qbb_spota_hc.py:29-38 as the kernels take it """
+    from simurlacra_amd.domain_randomization import UniformDomainParam, get_default_randomizer
+    from simurlacra_amd.environment_wrappers import DomainRandWrapperLive
+    from simurlacra_amd.sampling.batch import EnvPlan
+    env = QBallBalancerSim(dt=0.01, max_steps=50)
+    env = GaussianObsNoiseWrapper(env, noise_std=[1/180*np.pi, 1/180*np.pi, 0.005, 0.005, 10/180*np.pi, 10/180*np.pi, 0.05, 0.05])
+    env = ActNormWrapper(env)
+    env = ActDelayWrapper(env)
+    randomizer = get_default_randomizer(env)
+    randomizer.add_domain_params(UniformDomainParam(name='act_delay', mean=5, halfspan=5, clip_lo=0, roundint=True))
+    env = DomainRandWrapperLive(env, randomizer)
+    plan = EnvPlan(env)
+    spec = plan.wrap_spec(noise_seed=3, env_offset=7)
+    assert list(spec.ops) == ['act_delay', 'act_norm', 'obs_noise'] and spec.act_delay_row == 20 and plan.obs_dim == 8
+    c = spec.to_c(8, 2)
+    assert c.n_ops == 3 and list(c.ops)[:3] == [abi.WRAP_ACT_DELAY, abi.WRAP_ACT_NORM, abi.WRAP_OBS_NOISE]
+    assert c.obs_noise_std[7] == 0.05 and c.env_offset == 7 and np.isnan(c.obs_lo[0])
+    assert [d['row'] for d in randomizer.device_table(plan.names, plan.extra_rows)][-1] == 20
+    # partial observation outside the noise: vectors are re-indexed by the simulation's observation index
+    # QQube's velocities are unbounded: without overrides for both the reference refuses to normalise, and so does the plan
+    with pytest.raises(pyrado.ValueErr):
+        EnvPlan(ObsNormWrapper(QQubeSim(dt=0.004, max_steps=10), explicit_lb={r'$\dot{\theta}$': -20.})).wrap_spec()
+    env = ObsPartialWrapper(GaussianObsNoiseWrapper(QQubeSim(dt=0.004, max_steps=10), noise_std=[.1, .2, .3, .4, .5, .6]), idcs=[1])
+    spec = EnvPlan(env).wrap_spec()
+    assert list(spec.ops) == ['obs_partial', 'obs_noise'] and spec.obs_dim(6) == 5 and list(spec.obs_keep) == [1, 0, 1, 1, 1, 1]
+    with pytest.raises(NotImplementedError):
+        EnvPlan(ActNormWrapper(ActNormWrapper(QQubeSim(dt=0.004, max_steps=10))))
 
 
 # ------------------------------------------------------------------------------------------------ policies
