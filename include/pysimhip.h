@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 101
+#define PSH_VERSION 102
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -123,6 +123,8 @@ typedef enum psh_feat {
 
 typedef enum psh_nonlin { PSH_NL_NONE = 0, PSH_NL_TANH = 1, PSH_NL_RELU = 2, PSH_NL_SIGMOID = 3 } psh_nonlin;
 
+typedef enum psh_expl_kind { PSH_EXPL_NONE = 0, PSH_EXPL_NORMAL = 1, PSH_EXPL_UNIFORM = 2 } psh_expl_kind;
+
 typedef struct psh_policy {
     int32_t kind;                          /* psh_policy_kind */
     int32_t n_feats;                       /* LINEAR: length of feats[] */
@@ -136,6 +138,19 @@ typedef struct psh_policy {
     int32_t pad_;
     const double* params;                  /* [dev] [n_policies, num_param] row-major */
     const int32_t* policy_index;           /* [dev] [N] row of params used by env i, or NULL (row 0) */
+    /* Action-noise exploration around the policy, StochasticActionExplStrat.forward
+     * (Pyrado/pyrado/exploration/stochastic_action.py:42-68): the exploratory action is what the rollout records
+     * and what the environment chain receives.
+     *  NORMAL   NormalActNoiseExplStrat  (:96-136, exploration/normal_noise.py:100-108)
+     *           a + expl_mean + expl_scale * eps,  eps ~ N(0, 1);   expl_scale = std
+     *  UNIFORM  UniformActNoiseExplStrat (:139-176, exploration/uniform_noise.py)
+     *           lo + u (hi - lo) with lo/hi = a + expl_mean -/+ expl_scale, u ~ U[0, 1);   expl_scale = halfspan
+     * Drawn from Philox4x32-10 keyed like the wrapper noise (psh_wrappers.noise_seed / env_offset, step index),
+     * on a stream of its own. */
+    int32_t expl_kind;                     /* psh_expl_kind */
+    int32_t pad2_;
+    double expl_mean[PSH_MAX_ACT];
+    double expl_scale[PSH_MAX_ACT];
 } psh_policy;
 
 /* rollout flags */

@@ -525,6 +525,16 @@ static void step_normals(uint64_t seed, uint64_t env, uint32_t t, uint32_t strea
     }
 }
 
+/* two uniforms in [0, 1) for (seed, env, step t, stream) */
+static void step_uniforms(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double* out) {
+    uint32_t ctr[4] = {(uint32_t)env, (uint32_t)(env >> 32), t, stream};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    out[0] = u01(o[0], o[1]);
+    out[1] = u01(o[2], o[3]);
+}
+
 /* observation-space bounds of the simulation: pysim/quanser_qube.py:25-33, quanser_cartpole.py:45-50,
  * quanser_ball_balancer.py:73, ball_on_beam.py:32, one_mass_oscillator.py:39 */
 static void sim_obs_bounds(const orc_env* e, double* lo, double* hi) {
@@ -626,6 +636,22 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
         if (d->obs) for (int r = 0; r < OP; ++r) d->obs[((size_t)k * OP + r) * N + i] = obs[r];
         if (nan) { st |= PSH_ST_NAN; break; }
         policy_forward(&d->policy, pw, OP, A, obs, act);
+        if (d->policy.expl_kind == PSH_EXPL_NORMAL) {
+            /* NormalActNoiseExplStrat: Normal(a + mean, std).rsample() = loc + eps * scale
+             * (exploration/stochastic_action.py:55, normal_noise.py:100-108) */
+            double n[PSH_MAX_ACT];
+            step_normals(w->noise_seed, genv, (uint32_t)k, 3u, A, n);
+            for (int r = 0; r < A; ++r) act[r] = (act[r] + d->policy.expl_mean[r]) + n[r] * d->policy.expl_scale[r];
+        } else if (d->policy.expl_kind == PSH_EXPL_UNIFORM) {
+            /* UniformActNoiseExplStrat: Uniform(m - halfspan, m + halfspan).rsample() = low + u * (high - low) */
+            double u[2];
+            step_uniforms(w->noise_seed, genv, (uint32_t)k, 3u, u);
+            for (int r = 0; r < A; ++r) {
+                double m = act[r] + d->policy.expl_mean[r];
+                double lo = m - d->policy.expl_scale[r], hi = m + d->policy.expl_scale[r];
+                act[r] = lo + u[r] * (hi - lo);
+            }
+        }
         for (int r = 0; r < A; ++r) if (isnan(act[r])) nan = 1;
         if (nan) { st |= PSH_ST_NAN; break; }
         /* EnvWrapperAct.step, outermost wrapper first */

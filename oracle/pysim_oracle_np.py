@@ -454,6 +454,32 @@ def step_normals(seed, env, t, stream, n):
     return out
 
 
+def step_uniforms(seed, env, t, stream):
+    o = philox4x32_10((env & M32, (env >> 32) & M32, t, stream), (seed & M32, (seed >> 32) & M32))
+    return np.array([((o[0] >> 5)*67108864.0 + (o[1] >> 6))*(1.0/9007199254740992.0),
+                     ((o[2] >> 5)*67108864.0 + (o[3] >> 6))*(1.0/9007199254740992.0)])
+
+
+class ExplPolicyNp:
+    """ StochasticActionExplStrat.forward (exploration/stochastic_action.py:42-68) around a policy: Normal
+    (normal_noise.py:100-108) or Uniform (uniform_noise.py) action noise; one draw per call, indexed by the call count """
+
+    def __init__(self, policy, kind, mean, scale, seed, env_id):
+        self.policy, self.kind, self.seed, self.env_id, self.k = policy, kind, seed, env_id, 0
+        self.mean, self.scale = np.asarray(mean, float), np.asarray(scale, float)
+
+    def __call__(self, obs):
+        act = np.asarray(self.policy(obs), dtype=np.float64).reshape(-1)
+        if self.kind == 'normal':
+            act = (act + self.mean) + step_normals(self.seed, self.env_id, self.k, 3, act.shape[0])*self.scale
+        else:
+            m = act + self.mean
+            lo, hi = m - self.scale, m + self.scale
+            act = lo + step_uniforms(self.seed, self.env_id, self.k, 3)[:act.shape[0]]*(hi - lo)
+        self.k += 1
+        return act
+
+
 class NpWrapper:
     """ EnvWrapper (environment_wrappers/base.py:29-141): forwards everything to the wrapped env """
 

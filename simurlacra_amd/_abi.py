@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 101
+PSH_VERSION = 102
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -22,6 +22,7 @@ ENV_QQ, ENV_QCP_SU, ENV_QCP_ST, ENV_QBB, ENV_BOB, ENV_OMO = range(6)
 REW_QUADR, REW_EXP_QUADR, REW_SCALED_EXP_QUADR, REW_SWINGUP = range(4)
 FIN_ENABLED, FIN_ALWAYS_POSITIVE, FIN_ALWAYS_NEGATIVE, FIN_STATE_DEPENDENT, FIN_TIME_DEPENDENT = 1, 2, 4, 8, 16
 POL_LINEAR, POL_FNN = 0, 1
+EXPL_NONE, EXPL_NORMAL, EXPL_UNIFORM = 0, 1, 2
 FEAT_IDS = dict(const=0, identity=1, sign=2, abs=3, squared=4, cubed=5, sig=6, bell=7, sin=8, cos=9, sinsin=10,
                 sincos=11)
 NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
@@ -55,6 +56,7 @@ class PshPolicy(C.Structure):
         ('n_hidden', C.c_int32), ('hidden', C.c_int32*PSH_MAX_HIDDEN), ('hidden_nonlin', C.c_int32*PSH_MAX_HIDDEN),
         ('out_nonlin', C.c_int32), ('n_policies', C.c_int32), ('num_param', C.c_int32), ('pad_', C.c_int32),
         ('params', C.c_void_p), ('policy_index', C.c_void_p),
+        ('expl_kind', C.c_int32), ('pad2_', C.c_int32), ('expl_mean', C.c_double*PSH_MAX_ACT), ('expl_scale', C.c_double*PSH_MAX_ACT),
     ]
 
 

@@ -260,6 +260,25 @@ template <int KIND, bool WRAP> struct Lane {
     }
 
     PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act) {
+        if constexpr (WRAP) {
+            // StochasticActionExplStrat.forward (exploration/stochastic_action.py:42-68): the exploratory action
+            // replaces the policy's output for everything that follows
+            if (a.pol.expl_kind == PSH_EXPL_NORMAL) {
+                double n[E::A];
+                step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, n);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] = (act[r] + a.pol.expl_mean[r]) + n[r] * a.pol.expl_scale[r];
+            } else if (a.pol.expl_kind == PSH_EXPL_UNIFORM) {
+                double u[2];
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, u[0], u[1]);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) {
+                    const double m = act[r] + a.pol.expl_mean[r];
+                    const double lo = m - a.pol.expl_scale[r], hi = m + a.pol.expl_scale[r];
+                    act[r] = lo + u[r] * (hi - lo);
+                }
+            }
+        }
         bool nan = false;
 #pragma unroll
         for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
@@ -937,7 +956,8 @@ template <int KIND> static int launch_rollout(psh_ctx* c, const psh_rollout_desc
         const int rc = check_wrap(c, d->wrap, E::O, &Oe, &has_delay);
         if (rc != PSH_OK) return rc;
     }
-    const bool wrapped = d->wrap.n_ops > 0;
+    if (p.expl_kind < PSH_EXPL_NONE || p.expl_kind > PSH_EXPL_UNIFORM) { set_err(c, "unknown exploration kind"); return PSH_ERR_ARG; }
+    const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE;  // both live in the WRAP kernels
     a.obs_dim = Oe;
     if (p.kind == PSH_POL_LINEAR) {
         if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }

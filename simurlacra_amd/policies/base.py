@@ -67,3 +67,7 @@ class Policy(nn.Module, ABC):
         """ Description of this policy for the fused rollout kernels, or None when it has to be evaluated step by
         step through torch. """
         return None
+
+    def fused_params(self) -> to.Tensor:
+        """ The parameter vector the fused kernels read (the layout psh_policy.params documents). """
+        return self.param_values

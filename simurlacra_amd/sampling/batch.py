@@ -187,7 +187,7 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
         if spec.obs_dim != plan.obs_dim:
             raise ValueErr(msg=f'the policy takes {spec.obs_dim} observations, the environment yields {plan.obs_dim}')
         if params is None:
-            params = policy.param_values.detach().to(torch.float64)
+            params = policy.fused_params().detach().to(torch.float64)
         return eng.rollout(plan.kind, plan.sim.dt, T, task_c, spec, params, init_state, dp, flags=plan.flags(stop_on_done),
                            dp_index=dp_index, policy_index=policy_index, record=record, wrap=wrap)
     if params is not None:

@@ -77,6 +77,10 @@ class PolicySpec:
     hidden: Sequence[int] = field(default_factory=list)    # fnn: hidden sizes
     hidden_nonlin: Sequence[Optional[str]] = field(default_factory=list)
     out_nonlin: Optional[str] = None
+    # action-noise exploration around the policy (Pyrado/pyrado/exploration/stochastic_action.py:96-176)
+    expl_kind: Optional[str] = None                        # None | 'normal' | 'uniform'
+    expl_mean: Optional[Sequence[float]] = None
+    expl_scale: Optional[Sequence[float]] = None           # std / halfspan per action dimension
 
     @property
     def num_feat(self) -> int:
@@ -117,6 +121,14 @@ class PolicySpec:
             p.out_nonlin = abi.NL_IDS[self.out_nonlin]
         else:
             raise ValueError(self.kind)
+        p.expl_kind = {None: abi.EXPL_NONE, 'normal': abi.EXPL_NORMAL, 'uniform': abi.EXPL_UNIFORM}[self.expl_kind]
+        if self.expl_kind is not None:
+            mean = np.zeros(self.act_dim) if self.expl_mean is None else np.asarray(self.expl_mean, dtype=np.float64).reshape(-1)
+            scale = np.asarray(self.expl_scale, dtype=np.float64).reshape(-1)
+            if mean.size != self.act_dim or scale.size != self.act_dim:
+                raise ValueError('exploration mean / scale need one entry per action dimension')
+            for i in range(self.act_dim):
+                p.expl_mean[i], p.expl_scale[i] = mean[i], scale[i]
         p.n_policies = int(n_policies)
         p.num_param = self.num_param
         p.params = params_ptr

@@ -279,6 +279,35 @@ def test_non_fusable_policy_with_wrappers_matches_the_fused_path():
     assert cases.rel_err(a[3].actions, b[3].actions) <= TOL and cases.rel_err(a[3].observations, b[3].observations) <= TOL
 
 
+def test_exploration_strategy_runs_fused():
+    """ rollouts of NormalActNoiseExplStrat(policy) through the fused kernel: actions scatter around the policy's output
+    with the strategy's std (Pyrado/pyrado/exploration/stochastic_action.py:96-136), trajectories are complete, and
+    the strategy can re-evaluate them (evaluate() -> Normal centred at the noise-free actions). """
+    from simurlacra_amd.exploration import NormalActNoiseExplStrat, UniformActNoiseExplStrat
+    env = ENVS['qq'](50)
+    pol = FNNPolicy(env.spec, [32, 32], to.tanh)
+    expl = NormalActNoiseExplStrat(pol, std_init=0.7)
+    assert expl.fused_spec().expl_kind == 'normal' and expl.fused_params().numel() == pol.num_param
+    ros = ParallelSampler(env, expl, 1, min_rollouts=400, seed=2).sample()
+    obs = np.concatenate([ro.observations[:-1] for ro in ros])
+    act = np.concatenate([ro.actions for ro in ros])
+    with to.no_grad():
+        mean = pol(to.as_tensor(obs)).numpy()
+    resid = act - mean
+    assert abs(resid.std() - 0.7) < 0.03 and abs(resid.mean()) < 0.03
+    first = ros[0]
+    first.torch(data_type=to.float64)      # as the reference's algorithms do before evaluate()
+    dist = expl.evaluate(first)
+    assert cases.rel_err(dist.mean.detach().numpy(), mean[:len(ros[0])]) <= TOL and float(dist.stddev.detach()[0, 0]) == pytest.approx(0.7)
+    uni = UniformActNoiseExplStrat(pol, halfspan_init=0.5)
+    ros = ParallelSampler(env, uni, 1, min_rollouts=200, seed=2).sample()
+    obs = np.concatenate([ro.observations[:-1] for ro in ros])
+    act = np.concatenate([ro.actions for ro in ros])
+    with to.no_grad():
+        resid = act - pol(to.as_tensor(obs)).numpy()
+    assert resid.min() >= -0.5 and resid.max() <= 0.5 and abs(resid.std() - 0.5/np.sqrt(3)) < 0.02
+
+
 def test_param_expl_sampler():
     """ Pyrado/tests/test_sampling.py:287-326: rollout ri of every parameter set shares its domain parameters and its
     initial observation with rollout ri of every other set """

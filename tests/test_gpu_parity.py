@@ -97,6 +97,24 @@ def test_rollout_with_fused_wrappers(eng, orc, kind, wrap, policy):
     _compare_rollouts(eng, orc, case, T=T, wrap=wrap)
 
 
+@pytest.mark.parametrize('expl', ['normal', 'uniform'])
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+def test_rollout_with_action_noise_exploration(eng, orc, expl, policy):
+    """ NormalActNoiseExplStrat / UniformActNoiseExplStrat fused behind the policy forward, alone and in front of a
+    wrapper chain: same Philox draws as the oracle, so trajectories agree to the tolerance. """
+    import dataclasses
+    for kind, wrap in ((abi.ENV_QQ, cases.WrapSpec(noise_seed=8, env_offset=5)),
+                       (abi.ENV_QBB, cases.WrapSpec(ops=['act_delay', 'act_norm', 'obs_noise'], act_delay=2, noise_seed=11,
+                                                    obs_noise_std=[0.01]*8))):
+        S, O, A, P, _ = abi.ENV_DIMS[kind]
+        kw = dict(scale=0.3)
+        if policy == 'fnn':
+            kw['hidden'] = (64, 64)
+        case = cases.make_case(kind, 300, seed=91 + kind, policy=policy, **kw)
+        case['ps'] = dataclasses.replace(case['ps'], expl_kind=expl, expl_mean=[0.05]*A, expl_scale=[0.4]*A)
+        _compare_rollouts(eng, orc, case, T=40, wrap=wrap)
+
+
 def test_fused_delay_with_lane_refill(eng, orc):
     """ More envs than resident lanes and short episodes: lanes take over new envs, whose delay queues must start
     empty although the ring-buffer memory is reused. """

@@ -238,6 +238,36 @@ def test_c_and_numpy_agree_on_wrapper_chains(kind, wrap):
         assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-12
 
 
+@pytest.mark.parametrize('expl', ['normal', 'uniform'])
+def test_c_and_numpy_agree_with_action_noise_exploration(expl):
+    """ NormalActNoiseExplStrat / UniformActNoiseExplStrat (exploration/stochastic_action.py:42-68,96-176): the
+    exploratory action is recorded and applied; here also delayed and normalised by the wrappers behind it. """
+    import dataclasses
+    kind, n, T = abi.ENV_QBB, 3, 25
+    case = cases.make_case(kind, n, seed=21, policy='linear', scale=0.2)
+    ps = dataclasses.replace(case['ps'], expl_kind=expl, expl_mean=[0.1, -0.2], expl_scale=[0.3, 0.5])
+    wrap = WrapSpec(ops=['act_delay', 'act_norm'], act_delay=2, noise_seed=17, env_offset=40)
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], ps, case['params'], case['init'], case['dp'], record=True, wrap=wrap)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = np_wrapped_env(kind, case['dt'], T, wrap, 40 + i)
+        policy = onp.ExplPolicyNp(onp.LinearPolicyNp(ps.feats, case['params'].reshape(2, -1)), expl, [0.1, -0.2], [0.3, 0.5],
+                                  17, 40 + i)
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['act'][:L, :, i], ro['actions']) < 1e-12
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-12
+    # the noise has the requested moments
+    big = cases.make_case(abi.ENV_OMO, 4000, seed=2, policy='linear', feats=('const',), scale=0.0)
+    ps = dataclasses.replace(big['ps'], expl_kind=expl, expl_mean=[0.5], expl_scale=[2.0])
+    o = orc.rollout(abi.ENV_OMO, big['dt'], 1, big['task_c'], ps, big['params'], big['init'], big['dp'], record=True,
+                    wrap=WrapSpec(noise_seed=3))
+    a = o['act'][0, 0]
+    assert abs(a.mean() - 0.5) < 0.1 and abs(a.std() - (2.0 if expl == 'normal' else 2.0/np.sqrt(3))) < 0.1
+    assert expl == 'normal' or (a.min() >= -1.5 and a.max() < 2.5)
+
+
 def test_oracle_policy_forward_matches_torch():
     """ FNN.forward / LinearPolicy.forward against torch.nn.Linear in fp64 (policies/fnn.py:129-151) """
     import torch
