@@ -22,6 +22,12 @@ class SamplerBase:
             raise ValueErr(msg='At least one of min_rollouts or min_steps must be given')
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
 
+    def set_min_count(self, min_rollouts: int = None, min_steps: int = None):
+        """ SamplerBase.set_min_count (Pyrado/pyrado/sampling/sampler.py): change the amount to sample """
+        if min_rollouts is None and min_steps is None:
+            raise ValueErr(msg='At least one of min_rollouts or min_steps must be given')
+        self.min_rollouts, self.min_steps = min_rollouts, min_steps
+
 
 class ParallelSampler(SamplerBase):
     def __init__(self, env, policy, num_envs: int = 1, *, min_rollouts: int = None, min_steps: int = None,

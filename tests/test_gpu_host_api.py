@@ -308,6 +308,23 @@ def test_exploration_strategy_runs_fused():
     assert resid.min() >= -0.5 and resid.max() <= 0.5 and abs(resid.std() - 0.5/np.sqrt(3)) < 0.02
 
 
+def test_cvar_sampler_keeps_the_worst_quantile():
+    """ Pyrado/pyrado/sampling/cvar_sampler.py:9-107 on a batch: ranked on the device, 1/epsilon times as many sampled """
+    from simurlacra_amd.sampling import CVaRSampler, select_cvar
+    env = ENVS['bob'](40)
+    renv = DomainRandWrapperLive(env, get_default_randomizer(env))
+    pol = LinearPolicy(renv.spec, FeatureStack([identity_feat]))
+    inner = ParallelSampler(renv, pol, 1, min_rollouts=10, seed=1)
+    sub = CVaRSampler(inner, epsilon=0.2, min_rollouts=10).sample()
+    assert inner.min_rollouts == 50 and len(sub) == 10
+    full = ParallelSampler(renv, pol, 1, min_rollouts=50, seed=1).sample()
+    rets = np.sort(full.undiscounted_returns())
+    assert [ro.undiscounted_return() for ro in sub] == pytest.approx(list(rets[:10]))
+    disc = select_cvar(full, 0.1, gamma=0.9)
+    ref = sorted(ro.discounted_return(0.9) for ro in full)[:5]
+    assert [ro.discounted_return(0.9) for ro in disc] == pytest.approx(ref)
+
+
 def test_param_expl_sampler():
     """ Pyrado/tests/test_sampling.py:287-326: rollout ri of every parameter set shares its domain parameters and its
     initial observation with rollout ri of every other set """

@@ -422,3 +422,42 @@ def test_step_sequence_basics():
         StepSequence(observations=[], actions=[], rewards=[])
     with pytest.raises(ValueError):
         StepSequence(rewards=rew, actions=act)
+
+
+# ------------------------------------------------------------------------------------------ return statistics
+@pytest.mark.parametrize('epsilon', [1, 0.5, 0.1])
+@pytest.mark.parametrize('num_ro', [10, 20])
+def test_select_cvar(epsilon, num_ro):
+    """ Pyrado/tests/test_sampling.py:128-148 """
+    import random
+    from simurlacra_amd.sampling import select_cvar
+    rollouts = [StepSequence(rewards=[i], observations=[i], actions=[i]) for i in range(num_ro)]
+    ro_shuf = list(rollouts)
+    random.shuffle(ro_shuf)
+    ro_cv = select_cvar(ro_shuf, epsilon, 1)
+    cv = sum(map(lambda ro: ro.discounted_return(1), ro_cv))/len(ro_cv)
+    nq = int(num_ro*epsilon)
+    assert cv == sum(range(nq))/nq
+
+
+def test_bootstrapping():
+    """ Pyrado/tests/test_sampling.py:236-285: same resampling call sequence as the reference, so the interval can be
+    recomputed by hand from NumPy's generator """
+    from simurlacra_amd.sampling import bootstrap_ci
+    sample = np.array([30, 37, 36, 43, 42, 43, 43, 46, 41, 42])
+    m, ci = bootstrap_ci(sample, np.mean, num_reps=20, alpha=0.1, ci_sides=2, seed=123)
+    np.random.seed(123)
+    means = np.random.choice(sample, (sample.shape[0], 20), replace=True).mean(axis=0)
+    d_lo, d_up = np.percentile(means - sample.mean(), [5., 95.])
+    assert m == sample.mean() and ci == pytest.approx([sample.mean() - d_up, sample.mean() - d_lo])
+    x = np.random.default_rng(0).normal(10, 1, 40)
+    m, ci2 = bootstrap_ci(x, np.mean, num_reps=1000, alpha=0.05, ci_sides=2, seed=1)
+    assert ci2[0] < x.mean() < ci2[1] and 0.3 < ci2[1] - ci2[0] < 0.9          # about +-1.96/sqrt(40)
+    mb, _ = bootstrap_ci(x, np.mean, num_reps=1000, alpha=0.05, ci_sides=2, bias_correction=True, seed=1)
+    assert mb != m and abs(mb - m) < 0.05
+    _, ci1 = bootstrap_ci(x, np.mean, num_reps=768, alpha=0.05, ci_sides=1, seed=1)
+    assert ci1[0] == -np.inf and x.mean() < ci1[1] < ci2[1] + 0.1
+    _, cit = bootstrap_ci(x, np.mean, num_reps=768, alpha=0.05, ci_sides=2, studentized=True, seed=1)
+    assert cit[0] < x.mean() < cit[1]
+    with pytest.warns(UserWarning):
+        assert bootstrap_ci(np.ones(8), np.mean, num_reps=10, alpha=0.1, ci_sides=2, studentized=True)[1] == [-np.inf, np.inf]
