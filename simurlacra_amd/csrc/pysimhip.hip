@@ -103,6 +103,16 @@ static_assert(offsetof(RolloutArgs, wrap) == offsetof(RolloutArgs, task) + sizeo
 constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
 constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
 
+// The LDS copy is addressed through a base the compiler has to keep in ONE vector register (it cannot see through the
+// empty asm), so every field is a ds_read with an immediate offset.  Left to itself it materialises one scalar
+// address per field, runs out of scalar registers and moves each of them through v_readlane/v_mov before use.
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ const double* opaque_lds_base(double* p) {
+    lds_double* q = (lds_double*)p;
+    asm volatile("" : "+v"(q));
+    return (const double*)q;
+}
+
 __device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
     const double* src = reinterpret_cast<const double*>(&a.task);
     for (int j = threadIdx.x; j < TASK_DOUBLES; j += blockDim.x) dst[j] = src[j];
@@ -366,8 +376,9 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
     constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS;
     __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
     double* const lds_w = lds_lin;
-    const psh_task& task = *reinterpret_cast<const psh_task*>(lds_lin + W_DOUBLES);
-    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(lds_lin + W_DOUBLES + sizeof(psh_task) / 8);
+    const double* const task_base = opaque_lds_base(lds_lin + W_DOUBLES);
+    const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
     const int F = a.num_feat;
     const int Oe = WRAP ? a.obs_dim : E::O;  // observation entries the policy sees
     if (!PER_ENV) {
@@ -471,8 +482,9 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     double* const stage = lds + a.lds_doubles + wave * (OP * 64);
     double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
-    const psh_task& task = *reinterpret_cast<const psh_task*>(task_lds);
-    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_lds + sizeof(psh_task) / 8);
+    const double* const task_base = opaque_lds_base(task_lds);
+    const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
 
     for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
     for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
