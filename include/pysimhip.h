@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 102
+#define PSH_VERSION 103
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -60,7 +60,9 @@ typedef enum psh_status {
  *            V_thold_x_pos V_thold_x_neg V_thold_y_pos V_thold_y_neg offset_th_x offset_th_y
  *                                                       pysim/quanser_ball_balancer.py:131-152
  *  BOB  (8)  g m_ball r_ball m_beam l_beam d_beam c_frict ang_offset   pysim/ball_on_beam.py:49-56
- *  OMO  (3)  m k d                                      pysim/one_mass_oscillator.py:55-57   */
+ *  OMO  (3)  m k d                                      pysim/one_mass_oscillator.py:55-57
+ *  PEND (5)  g m_pole l_pole d_pole tau_max             pysim/pendulum.py:41-47
+ *  QQ_ST     as QQ                                      pysim/quanser_qube.py:222-271        */
 typedef enum psh_env_kind {
     PSH_ENV_QQ = 0,      /* QQubeSim (QQubeSwingUpSim)   S=4 O=6 A=1 P=10  init 4 */
     PSH_ENV_QCP_SU = 1,  /* QCartPoleSwingUpSim          S=4 O=5 A=1 P=14  init 4 */
@@ -68,7 +70,9 @@ typedef enum psh_env_kind {
     PSH_ENV_QBB = 3,     /* QBallBalancerSim             S=8 O=8 A=2 P=20  init 4 (polar-sampled x,y,xd,yd) or 8 */
     PSH_ENV_BOB = 4,     /* BallOnBeamSim                S=4 O=4 A=1 P=8   init 4 */
     PSH_ENV_OMO = 5,     /* OneMassOscillatorSim         S=2 O=2 A=1 P=3   init 2 */
-    PSH_ENV_COUNT = 6
+    PSH_ENV_PEND = 6,    /* PendulumSim                  S=2 O=3 A=1 P=5   init 2 (always the zero state) */
+    PSH_ENV_QQ_ST = 7,   /* QQubeStabSim                 S=4 O=4 A=1 P=10  init 4 (observes des - state) */
+    PSH_ENV_COUNT = 8
 } psh_env_kind;
 
 /* Reward functions, Pyrado/pyrado/tasks/reward_functions.py */
@@ -227,6 +231,8 @@ int psh_env_dims(int env_kind, int32_t dims[5]);
  *   QBallBalancerSim      pysim/quanser_ball_balancer.py:154-271 (+ IK at reset :181-195,413-480)
  *   BallOnBeamSim         pysim/ball_on_beam.py:58-98
  *   OneMassOscillatorSim  pysim/one_mass_oscillator.py:59-84
+ *   PendulumSim           pysim/pendulum.py:49-61
+ *   QQubeStabSim          pysim/quanser_qube.py:222-271 (dynamics of QQubeSim)
  * One GPU lane owns one environment; state, domain parameters and derived constants stay in
  * registers for the whole horizon. */
 typedef struct psh_rollout_desc {

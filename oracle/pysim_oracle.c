@@ -48,6 +48,8 @@ int orc_env_dims(int kind, int32_t d[5]) {
     case PSH_ENV_QBB: d[0] = 8; d[1] = 8; d[2] = 2; d[3] = 20; d[4] = 4; return 0;
     case PSH_ENV_BOB: d[0] = 4; d[1] = 4; d[2] = 1; d[3] = 8; d[4] = 4; return 0;
     case PSH_ENV_OMO: d[0] = 2; d[1] = 2; d[2] = 1; d[3] = 3; d[4] = 2; return 0;
+    case PSH_ENV_PEND: d[0] = 2; d[1] = 3; d[2] = 1; d[3] = 5; d[4] = 2; return 0;
+    case PSH_ENV_QQ_ST: d[0] = 4; d[1] = 4; d[2] = 1; d[3] = 10; d[4] = 4; return 0;
     }
     return -1;
 }
@@ -57,7 +59,8 @@ static void calc_constants_and_spaces(orc_env* e) {
     const double* p = e->dp;
     const double inf = INFINITY;
     switch (e->kind) {
-    case PSH_ENV_QQ: { /* pysim/quanser_qube.py:73-90 (constants), :20-36 (spaces) */
+    case PSH_ENV_QQ_ST:
+    case PSH_ENV_QQ: { /* pysim/quanser_qube.py:73-90 (constants), :20-36 (spaces); QQubeStabSim :230-255 */
         double g = p[0], Mr = p[3], Lr = p[4], Mp = p[6], Lp = p[7];
         double Jr = Mr * (Lr * Lr) / 12;
         double Jp = Mp * (Lp * Lp) / 12;
@@ -68,7 +71,17 @@ static void calc_constants_and_spaces(orc_env* e) {
         e->c[4] = 0.5 * Mp * Lp * g;
         double ms[4] = {115. / 180 * ORC_PI, 4 * ORC_PI, 20 * ORC_PI, 20 * ORC_PI};
         for (int i = 0; i < 4; ++i) { e->s_lo[i] = -ms[i]; e->s_hi[i] = ms[i]; }
+        if (e->kind == PSH_ENV_QQ_ST) {
+            const double stab_thold = 15 / 180. * ORC_PI;
+            e->s_lo[0] = -120. / 180 * ORC_PI; e->s_hi[0] = 120. / 180 * ORC_PI;
+            e->s_lo[1] = ORC_PI - stab_thold; e->s_hi[1] = ORC_PI + stab_thold;
+        }
         e->a_lo[0] = -p[9]; e->a_hi[0] = p[9];
+        break;
+    }
+    case PSH_ENV_PEND: { /* pysim/pendulum.py:17-28 */
+        e->s_lo[0] = -4 * ORC_PI; e->s_hi[0] = 4 * ORC_PI; e->s_lo[1] = -4 * ORC_PI; e->s_hi[1] = 4 * ORC_PI;
+        e->a_lo[0] = -p[4]; e->a_hi[0] = p[4];
         break;
     }
     case PSH_ENV_QCP_SU:
@@ -279,6 +292,14 @@ static void observe(const orc_env* e, double* obs) {
     case PSH_ENV_QCP_ST: /* pysim/quanser_cartpole.py:54-55 */
         obs[0] = s[0]; obs[1] = sin(s[1]); obs[2] = cos(s[1]); obs[3] = s[2]; obs[4] = s[3];
         break;
+    case PSH_ENV_PEND: /* pysim/pendulum.py:38-39 */
+        obs[0] = sin(s[0]); obs[1] = cos(s[0]); obs[2] = s[1];
+        break;
+    case PSH_ENV_QQ_ST: { /* pysim/quanser_qube.py:257-262: the error to the upright position */
+        const double des[4] = {0., ORC_PI, 0., 0.};
+        for (int i = 0; i < 4; ++i) obs[i] = des[i] - s[i];
+        break;
+    }
     default: /* environments/base.py:157-167 */
         for (int i = 0; i < e->S; ++i) obs[i] = s[i];
     }
@@ -289,6 +310,15 @@ static void step_dynamics(orc_env* e, double* act, double dt) {
     double* s = e->s;
     const double* p = e->dp;
     switch (e->kind) {
+    case PSH_ENV_PEND: { /* pysim/pendulum.py:49-61 */
+        double g = p[0], m_pole = p[1], l_pole = p[2], d_pole = p[3];
+        double th = s[0], th_dot = s[1];
+        double th_ddot = (act[0] - 0.5 * m_pole * g * l_pole * sin(th) - d_pole * th_dot) / (m_pole * (l_pole * l_pole) / 3.);
+        s[1] += th_ddot * dt;
+        s[0] += s[1] * dt;
+        break;
+    }
+    case PSH_ENV_QQ_ST:
     case PSH_ENV_QQ: { /* pysim/quanser_qube.py:92-142.  All four RK4 stages evaluate the accelerations at the
                           UN-ADVANCED state (:140), so they are computed once. */
         double km = p[2], Rm = p[1], Dr = p[5], Dp = p[8];
@@ -542,6 +572,11 @@ static void sim_obs_bounds(const orc_env* e, double* lo, double* hi) {
     case PSH_ENV_QQ: {
         const double m[6] = {1., 1., 1., 1., INFINITY, INFINITY};
         for (int r = 0; r < 6; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
+        break;
+    }
+    case PSH_ENV_PEND: { /* pysim/pendulum.py:22,26 */
+        const double m[3] = {1., 1., INFINITY};
+        for (int r = 0; r < 3; ++r) { lo[r] = -m[r]; hi[r] = m[r]; }
         break;
     }
     case PSH_ENV_QCP_SU:
@@ -906,6 +941,13 @@ int orc_sample_init(const psh_init_desc* d) {
         }
         case PSH_ENV_OMO:
             lo[0] = -0.75 * 1.; hi[0] = -0.65 * 1.; lo[1] = -0.01 * 10.; hi[1] = 0.01 * 10.;
+            break;
+        case PSH_ENV_PEND: /* SingularStateSpace(zeros), pysim/pendulum.py:23,27 */
+            lo[0] = hi[0] = 0.; lo[1] = hi[1] = 0.;
+            break;
+        case PSH_ENV_QQ_ST: /* pysim/quanser_qube.py:244-245 */
+            lo[0] = -5. / 180 * ORC_PI; hi[0] = 5. / 180 * ORC_PI; lo[1] = 175. / 180 * ORC_PI; hi[1] = 185. / 180 * ORC_PI;
+            lo[2] = hi[2] = 0.; lo[3] = hi[3] = 0.;
             break;
         }
         double v[4];

@@ -24,13 +24,15 @@ DP_KEYS = {
             'offset_th_x', 'offset_th_y'],
     'bob': ['g', 'm_ball', 'r_ball', 'm_beam', 'l_beam', 'd_beam', 'c_frict', 'ang_offset'],
     'omo': ['m', 'k', 'd'],
+    'pend': ['g', 'm_pole', 'l_pole', 'd_pole', 'tau_max'],
 }
-KIND_ID = {'qq': 0, 'qcp-su': 1, 'qcp-st': 2, 'qbb': 3, 'bob': 4, 'omo': 5}
+DP_KEYS['qq-st'] = DP_KEYS['qq']
+KIND_ID = {'qq': 0, 'qcp-su': 1, 'qcp-st': 2, 'qbb': 3, 'bob': 4, 'omo': 5, 'pend': 6, 'qq-st': 7}
 
 
 def nominal(kind: str, long: bool = False) -> dict:
     """ get_nominal_domain_param() of each simulation """
-    if kind == 'qq':  # pysim/quanser_qube.py:61-71
+    if kind in ('qq', 'qq-st'):  # pysim/quanser_qube.py:61-71
         v = [9.81, 8.4, 0.042, 0.095, 0.085, 5e-6, 0.024, 0.129, 1e-6, 4.]
         return dict(zip(DP_KEYS['qq'], v))
     if kind in ('qcp-su', 'qcp-st'):  # pysim/quanser_cartpole.py:57-81
@@ -45,6 +47,8 @@ def nominal(kind: str, long: bool = False) -> dict:
         return dict(zip(DP_KEYS['bob'], [9.81, 0.5, 0.1, 3., 2., 0.1, 0.05, 0.]))
     if kind == 'omo':  # pysim/one_mass_oscillator.py:53-57
         return dict(zip(DP_KEYS['omo'], [1., 30., 0.5]))
+    if kind == 'pend':  # pysim/pendulum.py:41-47
+        return dict(zip(DP_KEYS['pend'], [9.81, 1., 1., 0.05, 3.5]))
     raise KeyError(kind)
 
 
@@ -152,6 +156,10 @@ def default_task(kind: str) -> Task:
     if kind == 'omo':  # pysim/one_mass_oscillator.py:43-51
         return Task(np.zeros(2), 'quadr', np.diag([1e1, 1e-2]), np.diag([1e-6]),
                     final_mode=dict(always_negative=True), final_factor=1e3)
+    if kind == 'pend':  # pysim/pendulum.py:30-36 (the radial index is the velocity, as the reference has it)
+        return Task([PI, 0.], 'exp', np.diag([1e-0, 5e-3]), np.diag([1e-3]), radial_idcs=[1])
+    if kind == 'qq-st':  # pysim/quanser_qube.py:264-271
+        return Task([0., PI, 0., 0.], 'exp', np.diag([3., 4., 2., 2.]), np.diag([5e-2]), radial_idcs=[1])
     raise KeyError(kind)
 
 
@@ -196,7 +204,7 @@ class NpEnv:
     def _update(self):
         p = self.dp
         k = self.kind
-        if k == 'qq':
+        if k in ('qq', 'qq-st'):
             Jr = p['Mr']*p['Lr']**2/12
             Jp = p['Mp']*p['Lp']**2/12
             c = np.zeros(5)
@@ -208,6 +216,10 @@ class NpEnv:
             self.c = c
             ms = np.array([115./180*PI, 4*PI, 20*PI, 20*PI])
             self.s_lo, self.s_hi = -ms, ms
+            if k == 'qq-st':  # pysim/quanser_qube.py:230-247
+                th = 15/180.*PI
+                self.s_lo = np.array([-120./180*PI, PI - th, -20*PI, -20*PI])
+                self.s_hi = np.array([120./180*PI, PI + th, 20*PI, 20*PI])
             self.a_lo, self.a_hi = np.array([-p['max_volt']]), np.array([p['max_volt']])
         elif k in ('qcp-su', 'qcp-st'):
             self.J_pole = p['l_pole']**2*p['m_pole']/3.
@@ -239,6 +251,10 @@ class NpEnv:
             self.s_lo, self.s_hi = -ms, ms
             ma = np.array([p['l_beam']/2.*p['g']*3.])
             self.a_lo, self.a_hi = -ma, ma
+        elif k == 'pend':  # pysim/pendulum.py:17-28
+            ms = np.array([4*PI, 4*PI])
+            self.s_lo, self.s_hi = -ms, ms
+            self.a_lo, self.a_hi = np.array([-p['tau_max']]), np.array([p['tau_max']])
         elif k == 'omo':
             self.omega = np.sqrt(p['k']/p['m'])
             self.zeta = p['d']/(2.*np.sqrt(p['m']*p['k']))
@@ -253,6 +269,10 @@ class NpEnv:
             return np.array([np.sin(s[0]), np.cos(s[0]), np.sin(s[1]), np.cos(s[1]), s[2], s[3]])
         if self.kind in ('qcp-su', 'qcp-st'):
             return np.array([s[0], np.sin(s[1]), np.cos(s[1]), s[2], s[3]])
+        if self.kind == 'pend':  # pysim/pendulum.py:38-39
+            return np.array([np.sin(s[0]), np.cos(s[0]), s[1]])
+        if self.kind == 'qq-st':  # pysim/quanser_qube.py:257-262
+            return (np.array([0., PI, 0., 0.]) - s).copy()
         return s.copy()
 
     def reset(self, init_state, domain_param=None):
@@ -279,7 +299,12 @@ class NpEnv:
 
     def _dynamics(self, act):
         p, dt, k = self.dp, self.dt, self.kind
-        if k == 'qq':  # pysim/quanser_qube.py:92-142
+        if k == 'pend':  # pysim/pendulum.py:49-61
+            th, th_dot = self.state
+            th_ddot = (act - 0.5*p['m_pole']*p['g']*p['l_pole']*np.sin(th) - p['d_pole']*th_dot)/(p['m_pole']*p['l_pole']**2/3.)
+            self.state[1] += float(th_ddot[0])*dt
+            self.state[0] += self.state[1]*dt
+        elif k in ('qq', 'qq-st'):  # pysim/quanser_qube.py:92-142
             def dyn(x, u):
                 th, al, thd, ald = x
                 a = self.c[0] + self.c[1]*np.sin(al)**2
@@ -510,6 +535,9 @@ def _sim_obs_bounds(env: NpEnv):
         return -m, m
     if env.kind in ('qcp-su', 'qcp-st'):
         m = np.array([env.dp['l_rail']/2., 1., 1., np.inf, np.inf])
+        return -m, m
+    if env.kind == 'pend':
+        m = np.array([1., 1., np.inf])
         return -m, m
     return env.s_lo.copy(), env.s_hi.copy()
 

@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 102
+PSH_VERSION = 103
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -18,7 +18,7 @@ PSH_MAX_WRAP = 6
 
 PSH_OK, PSH_ERR_ARG, PSH_ERR_HIP, PSH_ERR_NODEV, PSH_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
-ENV_QQ, ENV_QCP_SU, ENV_QCP_ST, ENV_QBB, ENV_BOB, ENV_OMO = range(6)
+ENV_QQ, ENV_QCP_SU, ENV_QCP_ST, ENV_QBB, ENV_BOB, ENV_OMO, ENV_PEND, ENV_QQ_ST = range(8)
 REW_QUADR, REW_EXP_QUADR, REW_SCALED_EXP_QUADR, REW_SWINGUP = range(4)
 FIN_ENABLED, FIN_ALWAYS_POSITIVE, FIN_ALWAYS_NEGATIVE, FIN_STATE_DEPENDENT, FIN_TIME_DEPENDENT = 1, 2, 4, 8, 16
 POL_LINEAR, POL_FNN = 0, 1
@@ -33,7 +33,8 @@ WRAP_ACT_NORM, WRAP_ACT_DELAY, WRAP_ACT_NOISE, WRAP_OBS_NOISE, WRAP_OBS_NORM, WR
 
 # (S, O, A, P, init_dim) per env kind
 ENV_DIMS = {ENV_QQ: (4, 6, 1, 10, 4), ENV_QCP_SU: (4, 5, 1, 14, 4), ENV_QCP_ST: (4, 5, 1, 14, 4),
-            ENV_QBB: (8, 8, 2, 20, 4), ENV_BOB: (4, 4, 1, 8, 4), ENV_OMO: (2, 2, 1, 3, 2)}
+            ENV_QBB: (8, 8, 2, 20, 4), ENV_BOB: (4, 4, 1, 8, 4), ENV_OMO: (2, 2, 1, 3, 2),
+            ENV_PEND: (2, 3, 1, 5, 2), ENV_QQ_ST: (4, 4, 1, 10, 4)}
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -3,7 +3,7 @@
 //
 // Each Env<KIND> follows one SimPyEnv subclass of the reference (paths relative to
 // Pyrado/pyrado/environments/pysim/):
-//   QQ   quanser_qube.py:20-142          QCP  quanser_cartpole.py:41-124,252-269,307-318
+//   QQ   quanser_qube.py:20-142,222-271  QCP  quanser_cartpole.py:41-124,252-269,307-318   PEND pendulum.py:17-61
 //   QBB  quanser_ball_balancer.py:60-271,413-480   BOB  ball_on_beam.py:21-98   OMO  one_mass_oscillator.py:28-84
 // and the step / reward / termination logic follows base.py:119-201 with the tasks of
 // Pyrado/pyrado/tasks/{desired_state.py:82-128, reward_functions.py:167-303, final_reward.py:70-187}.
@@ -28,8 +28,9 @@ struct DpCol {
 template <int KIND> struct Env;
 
 // ------------------------------------------------------------------------------------------------ QQube
-template <> struct Env<PSH_ENV_QQ> {
-    static constexpr int S = 4, O = 6, A = 1, P = 10, I = 4, X = 0;
+// STAB: QQubeStabSim (quanser_qube.py:222-271), same dynamics, narrower state space, observes the error to upright
+template <bool STAB> struct EnvQQ {
+    static constexpr int S = 4, O = STAB ? 4 : 6, A = 1, P = 10, I = 4, X = 0;
     double s[4];
     double c0, c1, c2, c3, c4, km, Rm, rRm, Dr, Dp, max_volt;
     double sth, cth, sal, cal;  // sin/cos of s[0], s[1]: shared by observe() and the next dynamics()
@@ -48,19 +49,31 @@ template <> struct Env<PSH_ENV_QQ> {
     PSH_DEV void state_bounds(double* lo, double* hi) const {
         const double m[4] = {115. / 180 * PSH_PI, 4 * PSH_PI, 20 * PSH_PI, 20 * PSH_PI};
         for (int i = 0; i < 4; ++i) { lo[i] = -m[i]; hi[i] = m[i]; }
+        if (STAB) {
+            const double th = 15 / 180. * PSH_PI;
+            lo[0] = -120. / 180 * PSH_PI; hi[0] = 120. / 180 * PSH_PI;
+            lo[1] = PSH_PI - th; hi[1] = PSH_PI + th;
+        }
     }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -max_volt; hi[0] = max_volt; }
-    PSH_DEV void obs_bounds(double* lo, double* hi) const {  // quanser_qube.py:25-33
+    PSH_DEV void obs_bounds(double* lo, double* hi) const {  // quanser_qube.py:25-33; STAB :252
+        if (STAB) { state_bounds(lo, hi); return; }
         const double inf = __builtin_inf();
         for (int i = 0; i < 4; ++i) { lo[i] = -1.; hi[i] = 1.; }
-        lo[4] = lo[5] = -inf; hi[4] = hi[5] = inf;
+        lo[O - 2] = lo[O - 1] = -inf; hi[O - 2] = hi[O - 1] = inf;
     }
     PSH_DEV void refresh() { psh_sincos(s[0], &sth, &cth); psh_sincos(s[1], &sal, &cal); }
     PSH_DEV void reset(const double* init, int, bool) {
         for (int i = 0; i < 4; ++i) s[i] = init[i];
         refresh();
     }
-    PSH_DEV void observe(double* o) const { o[0] = sth; o[1] = cth; o[2] = sal; o[3] = cal; o[4] = s[2]; o[5] = s[3]; }
+    PSH_DEV void observe(double* o) const {
+        if (STAB) {
+            o[0] = 0. - s[0]; o[1] = PSH_PI - s[1]; o[2] = 0. - s[2]; o[3] = 0. - s[3];
+        } else {
+            o[0] = sth; o[1] = cth; o[2] = sal; o[3] = cal; o[O - 2] = s[2]; o[O - 1] = s[3];
+        }
+    }
     PSH_DEV void dynamics(double* act, double dt, bool) {
         const double thd = s[2], ald = s[3], u = act[0];
         const double s2al = 2. * sal * cal;  // sin(2 al)
@@ -86,6 +99,39 @@ template <> struct Env<PSH_ENV_QQ> {
         s[1] += w * (kv[0][1] + 2 * kv[1][1] + 2 * kv[2][1] + kv[3][1]);
         s[2] += w * (thdd + 2 * thdd + 2 * thdd + thdd);
         s[3] += w * (aldd + 2 * aldd + 2 * aldd + aldd);
+        refresh();
+    }
+};
+
+template <> struct Env<PSH_ENV_QQ> : EnvQQ<false> {};
+template <> struct Env<PSH_ENV_QQ_ST> : EnvQQ<true> {};
+
+// ---------------------------------------------------------------------------------------------- Pendulum
+template <> struct Env<PSH_ENV_PEND> {
+    static constexpr int S = 2, O = 3, A = 1, P = 5, I = 2, X = 0;
+    double s[2];
+    double hmgl, d_pole, tau_max, inertia;  // 0.5 m g l, damping, torque limit, m l^2 / 3
+    double sth, cth;
+
+    PSH_DEV void setup(const DpCol& p) {
+        const double g = p[0], m_pole = p[1], l_pole = p[2];
+        d_pole = p[3]; tau_max = p[4];
+        hmgl = 0.5 * m_pole * g * l_pole;
+        inertia = m_pole * (l_pole * l_pole) / 3.;
+    }
+    PSH_DEV void state_bounds(double* lo, double* hi) const { lo[0] = lo[1] = -4 * PSH_PI; hi[0] = hi[1] = 4 * PSH_PI; }
+    PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -tau_max; hi[0] = tau_max; }
+    PSH_DEV void obs_bounds(double* lo, double* hi) const {
+        const double inf = __builtin_inf();
+        lo[0] = lo[1] = -1.; hi[0] = hi[1] = 1.; lo[2] = -inf; hi[2] = inf;
+    }
+    PSH_DEV void refresh() { psh_sincos(s[0], &sth, &cth); }
+    PSH_DEV void reset(const double* init, int, bool) { s[0] = init[0]; s[1] = init[1]; refresh(); }
+    PSH_DEV void observe(double* o) const { o[0] = sth; o[1] = cth; o[2] = s[1]; }
+    PSH_DEV void dynamics(double* act, double dt, bool) {  // pendulum.py:49-61
+        const double th_ddot = (act[0] - hmgl * sth - d_pole * s[1]) / inertia;
+        s[1] += th_ddot * dt;
+        s[0] += s[1] * dt;
         refresh();
     }
 };

@@ -782,6 +782,14 @@ __global__ __launch_bounds__(256) void k_sample_init(const InitArgs a) {
         lo[2] = -0.02 * 10.; hi[2] = 0.02 * 10.; lo[3] = -0.02 * PSH_PI; hi[3] = 0.02 * PSH_PI;
         break;
     }
+    case PSH_ENV_PEND:  // SingularStateSpace(zeros), pendulum.py:23,27
+        I = 2;
+        for (int r = 0; r < 4; ++r) lo[r] = hi[r] = 0.;
+        break;
+    case PSH_ENV_QQ_ST:  // quanser_qube.py:244-245
+        lo[0] = -5. / 180 * PSH_PI; hi[0] = 5. / 180 * PSH_PI; lo[1] = 175. / 180 * PSH_PI; hi[1] = 185. / 180 * PSH_PI;
+        lo[2] = hi[2] = lo[3] = hi[3] = 0.;
+        break;
     default:  // OMO
         I = 2;
         lo[0] = -0.75 * 1.; hi[0] = -0.65 * 1.; lo[1] = -0.01 * 10.; hi[1] = 0.01 * 10.;
@@ -839,6 +847,8 @@ static bool dims_of(int kind, int32_t d[5]) {
     case PSH_ENV_QBB: d[0] = 8; d[1] = 8; d[2] = 2; d[3] = 20; d[4] = 4; return true;
     case PSH_ENV_BOB: d[0] = 4; d[1] = 4; d[2] = 1; d[3] = 8; d[4] = 4; return true;
     case PSH_ENV_OMO: d[0] = 2; d[1] = 2; d[2] = 1; d[3] = 3; d[4] = 2; return true;
+    case PSH_ENV_PEND: d[0] = 2; d[1] = 3; d[2] = 1; d[3] = 5; d[4] = 2; return true;
+    case PSH_ENV_QQ_ST: d[0] = 4; d[1] = 4; d[2] = 1; d[3] = 10; d[4] = 4; return true;
     }
     return false;
 }
@@ -1071,6 +1081,8 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     case PSH_ENV_QCP_ST: return launch_rollout<PSH_ENV_QCP_ST>(c, d, a, st);
     case PSH_ENV_QBB: return launch_rollout<PSH_ENV_QBB>(c, d, a, st);
     case PSH_ENV_BOB: return launch_rollout<PSH_ENV_BOB>(c, d, a, st);
+    case PSH_ENV_PEND: return launch_rollout<PSH_ENV_PEND>(c, d, a, st);
+    case PSH_ENV_QQ_ST: return launch_rollout<PSH_ENV_QQ_ST>(c, d, a, st);
     default: return launch_rollout<PSH_ENV_OMO>(c, d, a, st);
     }
 }
@@ -1112,6 +1124,8 @@ static int fill_step_args(psh_ctx* c, const psh_step_desc* d, StepArgs& a, int32
     case PSH_ENV_QCP_ST: hipLaunchKernelGGL((KERNEL<PSH_ENV_QCP_ST>), grid, block, 0, st, args); break; \
     case PSH_ENV_QBB: hipLaunchKernelGGL((KERNEL<PSH_ENV_QBB>), grid, block, 0, st, args); break;     \
     case PSH_ENV_BOB: hipLaunchKernelGGL((KERNEL<PSH_ENV_BOB>), grid, block, 0, st, args); break;     \
+    case PSH_ENV_PEND: hipLaunchKernelGGL((KERNEL<PSH_ENV_PEND>), grid, block, 0, st, args); break;   \
+    case PSH_ENV_QQ_ST: hipLaunchKernelGGL((KERNEL<PSH_ENV_QQ_ST>), grid, block, 0, st, args); break; \
     default: hipLaunchKernelGGL((KERNEL<PSH_ENV_OMO>), grid, block, 0, st, args); break;              \
     }
 

@@ -38,6 +38,12 @@ def get_default_randomizer_omo() -> DomainRandomizer:
     return DomainRandomizer(_normal(n, 'm', 3, 1e-3), _normal(n, 'k', 3, 1e-3), _normal(n, 'd', 3, 1e-3))
 
 
+def get_default_randomizer_pend() -> DomainRandomizer:
+    n = nominal_domain_param(abi.ENV_PEND)
+    return DomainRandomizer(_normal(n, 'g', 10, 1e-3), _normal(n, 'm_pole', 10, 1e-3), _normal(n, 'l_pole', 10, 1e-3),
+                            _normal(n, 'd_pole', 10, 1e-3), _normal(n, 'tau_max', 10, 1e-3))
+
+
 def get_default_randomizer_qbb() -> DomainRandomizer:
     n = nominal_domain_param(abi.ENV_QBB)
     return DomainRandomizer(
@@ -84,7 +90,9 @@ def get_uniform_masses_lengths_randomizer_qq(frac_halfspan: float) -> DomainRand
 
 _REGISTRY = {abi.ENV_BOB: get_default_randomizer_bob, abi.ENV_OMO: get_default_randomizer_omo,
              abi.ENV_QBB: get_default_randomizer_qbb, abi.ENV_QCP_SU: get_default_randomizer_qcp,
-             abi.ENV_QCP_ST: get_default_randomizer_qcp, abi.ENV_QQ: get_default_randomizer_qq}
+             abi.ENV_QCP_ST: get_default_randomizer_qcp, abi.ENV_QQ: get_default_randomizer_qq,
+             abi.ENV_PEND: get_default_randomizer_pend,
+             abi.ENV_QQ_ST: get_default_randomizer_qq}   # the reference finds QQubeSim's through the class hierarchy
 
 
 def get_default_randomizer(env) -> DomainRandomizer:

@@ -1,4 +1,4 @@
 from .base import Env
 from .sim_base import SimEnv
 from .pysim import (BallOnBeamSim, OneMassOscillatorSim, QBallBalancerKin, QBallBalancerSim, QCartPoleSim,
-                    QCartPoleStabSim, QCartPoleSwingUpSim, QQubeSim, QQubeSwingUpSim, SimPyEnv)
+                    QCartPoleStabSim, QCartPoleSwingUpSim, PendulumSim, QQubeSim, QQubeStabSim, QQubeSwingUpSim, SimPyEnv)

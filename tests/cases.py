@@ -7,11 +7,11 @@ import numpy as np
 from simurlacra_amd import _abi as abi, envdefs
 from simurlacra_amd.specs import WrapSpec, PolicySpec
 
-KINDS = [abi.ENV_QQ, abi.ENV_QCP_SU, abi.ENV_QCP_ST, abi.ENV_QBB, abi.ENV_BOB, abi.ENV_OMO]
+KINDS = [abi.ENV_QQ, abi.ENV_QCP_SU, abi.ENV_QCP_ST, abi.ENV_QBB, abi.ENV_BOB, abi.ENV_OMO, abi.ENV_PEND, abi.ENV_QQ_ST]
 KIND_NAMES = {abi.ENV_QQ: 'qq', abi.ENV_QCP_SU: 'qcp-su', abi.ENV_QCP_ST: 'qcp-st', abi.ENV_QBB: 'qbb',
-              abi.ENV_BOB: 'bob', abi.ENV_OMO: 'omo'}
+              abi.ENV_BOB: 'bob', abi.ENV_OMO: 'omo', abi.ENV_PEND: 'pend', abi.ENV_QQ_ST: 'qq-st'}
 DT = {abi.ENV_QQ: 0.004, abi.ENV_QCP_SU: 0.002, abi.ENV_QCP_ST: 0.002, abi.ENV_QBB: 0.01, abi.ENV_BOB: 0.01,
-      abi.ENV_OMO: 0.01}
+      abi.ENV_OMO: 0.01, abi.ENV_PEND: 0.02, abi.ENV_QQ_ST: 0.004}
 
 
 def domain_params(kind, n, rng, spread=0.1):
@@ -35,6 +35,10 @@ def init_states(kind, dp, rng):
     if kind == abi.ENV_QCP_SU:
         hw = np.array([.03, pi/180, .005, 2*pi/180])
         return rng.uniform(-1, 1, (4, n))*hw[:, None]
+    if kind == abi.ENV_PEND:   # the init space is the single zero state; the tests also start elsewhere
+        return np.stack([rng.uniform(-3., 3., n), rng.uniform(-1., 1., n)])
+    if kind == abi.ENV_QQ_ST:
+        return np.stack([rng.uniform(-5, 5, n)/180*pi, rng.uniform(175, 185, n)/180*pi, np.zeros(n), np.zeros(n)])
     if kind == abi.ENV_QCP_ST:
         return np.stack([rng.uniform(-.05, .05, n), pi + rng.uniform(-.13, .13, n), rng.uniform(-.05, .05, n),
                          rng.uniform(-.13, .13, n)])

@@ -49,7 +49,9 @@ def test_rollout_linear_policy(eng, orc, kind):
 @pytest.mark.parametrize('hidden', [(16, 16), (64, 64), (24,), (32, 20, 8)])
 def test_rollout_fnn_policy(eng, orc, kind, hidden):
     case = cases.make_case(kind, 200, seed=101 + kind, policy='fnn', hidden=hidden)
-    _compare_rollouts(eng, orc, case, T=50)
+    # QQubeStabSim sits at an unstable equilibrium: with a random 64x64 policy the oracle's own response to a one-ulp
+    # change of the initial state reaches 1.6e-10 after 50 steps (1e-11 after 30), so its horizon is shorter
+    _compare_rollouts(eng, orc, case, T=30 if kind == abi.ENV_QQ_ST else 50)
 
 
 @pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB])

@@ -17,8 +17,9 @@ from simurlacra_amd.environment_wrappers import (GaussianActNoiseWrapper, Gaussi
 from simurlacra_amd.environment_wrappers import (ActDelayWrapper, ActNormWrapper, DomainRandWrapperBuffer,
                                                  DomainRandWrapperLive, MetaDomainRandWrapper, inner_env,
                                                  remove_all_dr_wrappers, typed_env)
-from simurlacra_amd.environments import (BallOnBeamSim, OneMassOscillatorSim, QBallBalancerSim, QCartPoleStabSim,
-                                         QCartPoleSwingUpSim, QQubeSim, QQubeSwingUpSim, SimEnv)
+from simurlacra_amd.environments import (BallOnBeamSim, OneMassOscillatorSim, PendulumSim, QBallBalancerSim,
+                                         QCartPoleStabSim, QCartPoleSwingUpSim, QQubeSim, QQubeStabSim, QQubeSwingUpSim,
+                                         SimEnv)
 from simurlacra_amd.policies import (FeatureStack, FNNPolicy, LinearPolicy, const_feat, identity_feat, squared_feat)
 from simurlacra_amd.sampling import ParallelRolloutSampler, ParallelSampler, StepSequence
 from simurlacra_amd.spaces import BoxSpace, CompoundSpace, Polar2DPosVelSpace
@@ -28,7 +29,8 @@ from simurlacra_amd.utils.data_types import EnvSpec
 
 ENVS = [lambda: QQubeSim(dt=0.004, max_steps=100), lambda: QCartPoleSwingUpSim(dt=0.002, max_steps=100),
         lambda: QCartPoleStabSim(dt=0.002, max_steps=100), lambda: QBallBalancerSim(dt=0.01, max_steps=100),
-        lambda: BallOnBeamSim(dt=0.01, max_steps=100), lambda: OneMassOscillatorSim(dt=0.01, max_steps=100)]
+        lambda: BallOnBeamSim(dt=0.01, max_steps=100), lambda: OneMassOscillatorSim(dt=0.01, max_steps=100),
+        lambda: PendulumSim(dt=0.02, max_steps=100), lambda: QQubeStabSim(dt=0.004, max_steps=100)]
 
 
 class MockEnv(SimEnv):
@@ -148,6 +150,12 @@ def test_default_tasks_translate_to_the_kernel_spec(make):
         assert c.final_mode == abi.FIN_ENABLED | abi.FIN_STATE_DEPENDENT | abi.FIN_TIME_DEPENDENT
     if env.kind == abi.ENV_OMO:
         assert c.rew_kind == abi.REW_QUADR and c.final_factor == 1e3
+    if env.kind == abi.ENV_PEND:      # the radial index of the reference's pendulum task is the velocity
+        assert c.rew_kind == abi.REW_EXP_QUADR and c.radial_mask == 2 and c.state_des[0] == np.pi
+        assert np.all(env.init_space.sample_uniform() == 0.) and env.act_space.bound_up[0] == 3.5
+    if env.kind == abi.ENV_QQ_ST:
+        assert c.Q[0] == 3. and c.R[0] == 5e-2 and env.obs_space is env.state_space
+        np.testing.assert_allclose(env.observe(np.array([0.1, 3., 1., 2.])), [-0.1, np.pi - 3., -1., -2.])
 
 
 def test_unsupported_tasks_are_rejected():

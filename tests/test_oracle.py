@@ -173,7 +173,7 @@ def test_c_and_numpy_agree_with_action_delay_on_qbb():
 
 
 NP_KIND = {abi.ENV_QQ: 'qq', abi.ENV_QCP_SU: 'qcp-su', abi.ENV_QCP_ST: 'qcp-st', abi.ENV_QBB: 'qbb', abi.ENV_BOB: 'bob',
-           abi.ENV_OMO: 'omo'}
+           abi.ENV_OMO: 'omo', abi.ENV_PEND: 'pend', abi.ENV_QQ_ST: 'qq-st'}
 
 
 def np_wrapped_env(kind, dt, T, wrap: WrapSpec, env_id):

@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 only = sys.argv[2] if len(sys.argv) > 2 else ''
 eng = get_engine(0)
 names = {abi.ENV_QQ: 'QQ', abi.ENV_QCP_SU: 'QCP_SU', abi.ENV_QCP_ST: 'QCP_ST', abi.ENV_QBB: 'QBB', abi.ENV_BOB: 'BOB',
-         abi.ENV_OMO: 'OMO'}
+         abi.ENV_OMO: 'OMO', abi.ENV_PEND: 'PEND', abi.ENV_QQ_ST: 'QQ_ST'}
 for kind in cases.KINDS:
     for pol in ('linear', 'fnn'):
         if only and only != pol:
