@@ -1,0 +1,674 @@
+// The fused rollout kernels (reset + T x (policy forward, SimPyEnv.step) per environment lane) and their launch logic,
+// as templates over the environment kind.  Each kind is instantiated in a translation unit of its own
+// (rollout_kind.hip compiled with -DPSH_KIND=<k>), so the kinds build in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#include "psh_ctx.h"
+#include "psh_env.h"
+#include "psh_rng.h"
+
+// ------------------------------------------------------------------------------------------ kernel arguments
+struct RolloutArgs {
+    int n_envs, max_steps, flags, init_dim;
+    double dt;
+    const double* init_state; long ld_init;
+    const double* domain_param; const int* dp_index; long ld_dp;
+    psh_task task;
+    psh_wrappers wrap;     // directly behind `task`: the two are staged into LDS as one block
+    psh_policy pol;
+    int obs_dim;           // entries of the observation the policy sees (all, or those kept by OBS_PARTIAL)
+    double* delay_q;       // ACT_DELAY: ring buffers [PSH_MAX_DELAY][A][n_lanes], one column per resident lane
+    long n_lanes;
+    int num_feat;          // LINEAR: total feature count F
+    int lds_doubles;       // FNN: doubles of the packed weight image
+    const double* wfrag;   // FNN: packed weight image (device)
+    double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
+    unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
+    const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
+    const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
+    int tanh_n;              // its length (fine or coarse table)
+};
+
+// The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
+// pulled into scalar registers for the whole loop and spill.
+static_assert(sizeof(psh_task) % 8 == 0 && sizeof(psh_wrappers) % 8 == 0, "staged as doubles");
+static_assert(offsetof(RolloutArgs, wrap) == offsetof(RolloutArgs, task) + sizeof(psh_task), "staged as one block");
+constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
+constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
+
+// The LDS copy is addressed through a base the compiler has to keep in ONE vector register (it cannot see through the
+// empty asm), so every field is a ds_read with an immediate offset.  Left to itself it materialises one scalar
+// address per field, runs out of scalar registers and moves each of them through v_readlane/v_mov before use.
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ const double* opaque_lds_base(double* p) {
+    lds_double* q = (lds_double*)p;
+    asm volatile("" : "+v"(q));
+    return (const double*)q;
+}
+
+__device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
+    const double* src = reinterpret_cast<const double*>(&a.task);
+    for (int j = threadIdx.x; j < TASK_DOUBLES; j += blockDim.x) dst[j] = src[j];
+}
+
+// ------------------------------------------------------------------------------------------------ math helpers
+PSH_DEV double nl_apply(int nl, double v) {
+    switch (nl) {
+    case PSH_NL_TANH: return psh_tanh(v);
+    case PSH_NL_RELU: return v > 0. ? v : 0.;
+    case PSH_NL_SIGMOID: return psh_sigmoid(v);
+    default: return v;
+    }
+}
+
+PSH_DEV double feat_apply(int id, double x) {
+    switch (id) {
+    case PSH_FEAT_SIGN: return (double)((x > 0.) - (x < 0.));
+    case PSH_FEAT_ABS: return fabs(x);
+    case PSH_FEAT_SQUARED: return x * x;
+    case PSH_FEAT_CUBED: return x * x * x;
+    case PSH_FEAT_SIG: return psh_sigmoid(x);
+    case PSH_FEAT_BELL: return psh_exp(-(x * x));
+    case PSH_FEAT_SIN: { double s, c; psh_sincos(x, &s, &c); return s; }
+    case PSH_FEAT_COS: { double s, c; psh_sincos(x, &s, &c); return c; }
+    case PSH_FEAT_SINSIN: { double s, c; psh_sincos(x, &s, &c); return s * s; }
+    case PSH_FEAT_SINCOS: { double s, c; psh_sincos(x, &s, &c); return s * c; }
+    default: return x;  // identity
+    }
+}
+
+// ------------------------------------------------------------------------------------------ one lane = one env
+// n standard normals for (seed, env, step, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p
+template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double* out) {
+#pragma unroll
+    for (int p = 0; 2 * p < N; ++p) {
+        double ua, ub, sn, cs;
+        psh_draw2(seed, env, t, stream + 16u * p, ua, ub);
+        const double r = sqrt(-2.0 * log(1.0 - ua));
+        sincos(2.0 * PSH_PI * ub, &sn, &cs);
+        out[2 * p] = r * cs;
+        if (2 * p + 1 < N) out[2 * p + 1] = r * sn;
+    }
+}
+
+// WRAP = true adds the fused environment wrappers (psh_wrappers) around the simulation; the bare variant carries
+// none of that code or state.
+template <int KIND, bool WRAP> struct Lane {
+    using E = Env<KIND>;
+    E e;
+    double c_max, ret;
+    long i;           // env this lane currently runs, -1: none
+    int curr_step, yielded, st, k;
+    int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
+    bool done, live;  // live: this lane still has steps to execute
+    bool exhausted;   // the work queue had nothing left for this lane
+    bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
+
+    PSH_DEV void init() { i = -1; live = false; exhausted = false; }
+
+    // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
+    // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
+    // an env has no influence on its results.
+    PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+        if (i >= 0 && !live) { store(a, wrap); i = -1; }
+        if (i < 0 && !exhausted) {
+            const unsigned int nxt = atomicAdd(a.queue, 1u);
+            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a, task, wrap); } else { exhausted = true; }
+        }
+    }
+
+    PSH_DEV void load(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+        const long col = a.dp_index ? (long)a.dp_index[i] : i;
+        const DpCol p{a.domain_param, a.ld_dp, col};
+        e.setup(p);
+        c_max = task_c_max<KIND>(e, task);
+        double init[E::S];
+        for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * a.ld_init + i] : 0.;
+        if constexpr (KIND == PSH_ENV_QBB) {
+            e.reset(init, a.init_dim, true);  // plate angles come from the IK prologue kernel
+            if (a.plate) { e.plate[0] = a.plate[i]; e.plate[1] = a.plate[(long)a.n_envs + i]; }
+        } else {
+            e.reset(init, a.init_dim, false);
+        }
+        ret = 0.; curr_step = 0; yielded = 0; st = 0; k = 0; done = false;
+        live = a.max_steps > 0;
+        if constexpr (WRAP) {
+            bool has_delay = false, new_array = false;
+            for (int j = 0; j < wrap.n_ops; ++j) {
+                has_delay = has_delay || wrap.ops[j] == PSH_WRAP_ACT_DELAY;
+                new_array = new_array || wrap.ops[j] == PSH_WRAP_ACT_NORM || wrap.ops[j] == PSH_WRAP_ACT_NOISE;
+            }
+            delay = 0; qpos = 0;
+            if (has_delay) {  // ActDelayWrapper.reset / _load_domain_param (action_delay.py:46-64)
+                delay = wrap.act_delay_row >= 0 ? (int)a.domain_param[wrap.act_delay_row * a.ld_dp + col] : wrap.act_delay;
+                delay = delay < 0 ? 0 : (delay > PSH_MAX_DELAY ? PSH_MAX_DELAY : delay);
+            }
+            rec_alias = !new_array;
+        }
+    }
+
+    // EnvWrapperObs.reset/step (environment_wrappers/base.py:216-231): the simulation's observation through the
+    // observation wrappers, innermost first; `out` receives the kept entries in order, zero padded
+    PSH_DEV void wrapped_obs(const RolloutArgs& a, const psh_wrappers& wrap, uint32_t t, double* out) const {
+        double o[E::O];
+        e.observe(o);
+        int keep = (1 << E::O) - 1;
+        for (int j = wrap.n_ops - 1; j >= 0; --j) {
+            const int op = wrap.ops[j];
+            if (op == PSH_WRAP_OBS_NOISE) {
+                double n[E::O];
+                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, t, 1u, n);
+#pragma unroll
+                for (int r = 0; r < E::O; ++r) o[r] = o[r] + (n[r] * wrap.obs_noise_std[r] + wrap.obs_noise_mean[r]);
+            } else if (op == PSH_WRAP_OBS_NORM) {
+                double lo[E::O], hi[E::O];
+                e.obs_bounds(lo, hi);
+#pragma unroll
+                for (int r = 0; r < E::O; ++r) {
+                    const double l = wrap.obs_lo[r], h = wrap.obs_hi[r];
+                    lo[r] = (l != l) ? lo[r] : l;
+                    hi[r] = (h != h) ? hi[r] : h;
+                    o[r] = (o[r] - lo[r]) / (hi[r] - lo[r]) * 2 - 1;
+                }
+            } else if (op == PSH_WRAP_OBS_PARTIAL) {
+                keep = wrap.obs_keep_mask;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) out[r] = 0.;
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) {
+            if (keep & (1 << r)) {
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) out[q] = (q == n) ? o[r] : out[q];  // out[n] = o[r] without dynamic indexing
+                n += 1;
+            }
+        }
+    }
+
+    // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
+    PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs) {
+        if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+        const int Oe = WRAP ? a.obs_dim : E::O;
+        bool nan = false;
+#pragma unroll
+        for (int r = 0; r < E::O; ++r) nan = nan || (r < Oe && obs[r] != obs[r]);
+        if (a.obs) {
+#pragma unroll
+            for (int r = 0; r < E::O; ++r)
+                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
+        }
+        if (nan) { st |= PSH_ST_NAN; live = false; }
+    }
+
+    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act) {
+        if constexpr (WRAP) {
+            // StochasticActionExplStrat.forward (exploration/stochastic_action.py:42-68): the exploratory action
+            // replaces the policy's output for everything that follows
+            if (a.pol.expl_kind == PSH_EXPL_NORMAL) {
+                double n[E::A];
+                step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, n);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] = (act[r] + a.pol.expl_mean[r]) + n[r] * a.pol.expl_scale[r];
+            } else if (a.pol.expl_kind == PSH_EXPL_UNIFORM) {
+                double u[2];
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, u[0], u[1]);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) {
+                    const double m = act[r] + a.pol.expl_mean[r];
+                    const double lo = m - a.pol.expl_scale[r], hi = m + a.pol.expl_scale[r];
+                    act[r] = lo + u[r] * (hi - lo);
+                }
+            }
+        }
+        bool nan = false;
+#pragma unroll
+        for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
+        if (nan) { st |= PSH_ST_NAN; live = false; return; }
+        const bool simplified = (a.flags & PSH_F_SIMPLIFIED_DYN) != 0;
+        double rew;
+        if constexpr (WRAP) {
+            // EnvWrapperAct.step (environment_wrappers/base.py:168-174), outermost wrapper first
+            double inner[E::A];
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) inner[r] = act[r];
+            for (int j = 0; j < wrap.n_ops; ++j) {
+                const int op = wrap.ops[j];
+                if (op == PSH_WRAP_ACT_DELAY && delay > 0) {  // FIFO as a ring: the slot written now is read `delay` steps on
+                    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) {
+                        double* q = a.delay_q + ((long)qpos * E::A + r) * a.n_lanes + slot;
+                        const double old = (k >= delay) ? *q : 0.;
+                        *q = inner[r];
+                        inner[r] = old;
+                    }
+                    qpos = (qpos + 1 == delay) ? 0 : qpos + 1;
+                } else if (op == PSH_WRAP_ACT_NORM) {
+                    double lo[E::A], hi[E::A];
+                    e.act_bounds(lo, hi);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
+                } else if (op == PSH_WRAP_ACT_NOISE) {
+                    double n[E::A];
+                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 2u, n);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
+                }
+            }
+            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+                // ActDelayWrapper queues the caller's array objects: without an array-creating wrapper the simulation
+                // wrote its dead zone (QBB) into the action recorded `delay` steps ago
+                if (rec_alias && k - delay >= 0) {
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) a.act[((long)(k - delay) * E::A + r) * a.n_envs + i] = inner[r];
+                }
+            }
+        } else {
+            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+            }
+        }
+        if (a.rew) a.rew[(long)k * a.n_envs + i] = rew;
+        ret += rew;
+        k += 1;
+        if (st & PSH_ST_NAN) live = false;
+        if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
+    }
+
+    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap) {
+        if (a.obs) {  // final observation
+            double obs[E::O];
+            if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+            const int Oe = WRAP ? a.obs_dim : E::O;
+#pragma unroll
+            for (int r = 0; r < E::O; ++r)
+                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
+        }
+        a.ret[i] = ret;
+        a.length[i] = k;
+        a.status[i] = st;
+        if (a.final_state) {
+#pragma unroll
+            for (int r = 0; r < E::S; ++r) a.final_state[(long)r * a.n_envs + i] = e.s[r];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------- LinearPolicy rollouts
+// PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] of params.
+template <int KIND, bool PER_ENV, bool WRAP>
+__global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
+    using E = Env<KIND>;
+    constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS;
+    __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
+    double* const lds_w = lds_lin;
+    const double* const task_base = opaque_lds_base(lds_lin + W_DOUBLES);
+    const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
+    const int F = a.num_feat;
+    const int Oe = WRAP ? a.obs_dim : E::O;  // observation entries the policy sees
+    if (!PER_ENV) {
+        for (int j = threadIdx.x; j < E::A * F; j += blockDim.x) lds_w[j] = a.pol.params[j];
+    }
+    stage_task(a, lds_lin + W_DOUBLES);
+    __syncthreads();
+    Lane<KIND, WRAP> L;
+    L.init();
+    const double* w = lds_w;
+    long w_env = -1;
+    for (;;) {
+        asm volatile("" ::: "memory");  // keep the LDS constants out of registers across iterations
+        L.turnover(a, task, wrap);
+        if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
+        if (L.i < 0) continue;
+        if (PER_ENV && w_env != L.i) {
+            w = a.pol.params + (long)(a.pol.policy_index ? a.pol.policy_index[L.i] : 0) * a.pol.num_param;
+            w_env = L.i;
+        }
+        double obs[E::O], act[E::A];
+        L.pre_policy(a, wrap, obs);
+        if (!L.live) continue;
+#pragma unroll
+        for (int r = 0; r < E::A; ++r) act[r] = 0.;
+        int n = 0;
+        for (int f = 0; f < a.pol.n_feats; ++f) {
+            const int id = a.pol.feats[f];
+            if (id == PSH_FEAT_CONST) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n];
+                n += 1;
+            } else {
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) {
+                    if (WRAP && q >= Oe) break;
+                    const double v = feat_apply(id, obs[q]);
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * v;
+                }
+                n += Oe;
+            }
+        }
+        L.post_policy(a, task, wrap, act);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- FNNPolicy rollouts
+// Transposed formulation H^T[hidden, env] = W[hidden, k] . X^T[k, env] on v_mfma_f64_16x16x4_f64:
+//   A operand: lane l holds W[16t + (l & 15)][4s + (l >> 4)]           (weights, read from LDS)
+//   B operand: lane l holds X[k = 4s + (l >> 4)][env = l & 15]          (activations of 16 envs)
+//   D result : lane l, reg r holds H[16t + 4r + (l >> 4)][env = l & 15]
+// so reg r of output tile t IS the B operand of k-step 4t + r of the next layer: layers chain without any
+// cross-lane movement.  A wave owns 64 envs (lane = env for the dynamics) and runs the policy as 4 tiles of 16
+// envs; only the observations (through an LDS staging row per wave) and the action (two xor-shuffles) cross lanes.
+//
+// On gfx950 the fp64 MFMA and the fp64 vector instructions share one pipe (64 and 4 cycles per instruction, no
+// overlap, also not between waves), so every vector instruction next to the MFMAs costs throughput: the activation
+// function is the table-based psh_tanh_tab and the loop keeps its constants in LDS rather than in registers.
+//
+// Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = OP/4 with OP = observation rows padded to 4:
+//   [HT*K0 frags of 64][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then [Wout: A*HP][bout: 2]
+// Dynamic LDS: [weight image][8 staging areas of OP*64][tanh table][task].  FINE selects the fine tanh table (40 KB);
+// the widest, deepest networks leave no room for it and run with the coarse one.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
+    if (nl == PSH_NL_TANH) {
+        if (FINE) {
+            // all table loads first, then the arithmetic: the LDS latency is paid once per layer, not per element
+            constexpr int CH = N < 8 ? N : 8;  // chunked: d and T of a whole layer would not fit the register file
+#pragma unroll
+            for (int m0 = 0; m0 < N; m0 += CH) {
+                double d[CH], T[CH];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) T[m] = tanh_tab[psh_tanh8_index(y[m0 + m], &d[m])];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
+        }
+    } else if (nl == PSH_NL_SIGMOID) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) y[m] = psh_sigmoid(y[m]);
+    } else if (nl == PSH_NL_RELU) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) y[m] = y[m] > 0. ? y[m] : 0.;
+    }
+}
+
+template <int KIND, int HP, bool FINE, bool WRAP>
+__global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
+    using E = Env<KIND>;
+    constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const w_lds = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    double* const stage = lds + a.lds_doubles + wave * (OP * 64);
+    double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
+    double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
+    const double* const task_base = opaque_lds_base(task_lds);
+    const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
+    const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
+
+    for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
+    stage_task(a, task_lds);
+    __syncthreads();
+
+    Lane<KIND, WRAP> L;
+    L.init();
+
+    const int n_hidden = a.pol.n_hidden;
+    for (;;) {
+        L.turnover(a, task, wrap);
+        if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
+        double obs[OP], act[E::A];
+#pragma unroll
+        for (int r = 0; r < OP; ++r) obs[r] = 0.;
+        if (L.live) L.pre_policy(a, wrap, obs);
+        if (!__any(L.live)) continue;
+        // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
+#pragma unroll
+        for (int r = 0; r < OP; ++r) stage[r * 64 + lane] = obs[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (int tile = 0; tile < 4; ++tile) {
+            double y[KS];
+            // layer 0
+            {
+                double xin[K0];
+#pragma unroll
+                for (int s = 0; s < K0; ++s) xin[s] = stage[(4 * s + q) * 64 + 16 * tile + c];
+                const double* wl = w_lds;
+                const double* bl = w_lds + HT * K0 * 64;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+#pragma unroll
+                    for (int s = 0; s < K0; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * K0 + s) * 64 + lane], xin[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
+                }
+                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[0], y, tanh_tab);
+            }
+            // further hidden layers
+            int off = HT * K0 * 64 + HP;
+            for (int l = 1; l < n_hidden; ++l) {
+                double x[KS];
+#pragma unroll
+                for (int m = 0; m < KS; ++m) x[m] = y[m];
+                const double* wl = w_lds + off;
+                const double* bl = wl + HT * KS * 64;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
+                }
+                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[l], y, tanh_tab);
+                off += HT * KS * 64 + HP;
+            }
+            // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
+            const double* wo = w_lds + off;
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) {
+                double p = 0.;
+#pragma unroll
+                for (int m = 0; m < KS; ++m) p += wo[r * HP + (m >> 2) * 16 + (m & 3) * 4 + q] * y[m];
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                p += wo[E::A * HP + r];
+                nl_apply_all<1, FINE>(a.pol.out_nonlin, &p, tanh_tab);
+                if (q == tile) act[r] = p;
+            }
+        }
+        if (L.live) L.post_policy(a, task, wrap, act);
+    }
+}
+
+// Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
+template <int KIND>
+__global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict__ out, int total, int O, int A, int HP,
+                           int OP, int n_hidden, int h0, int h1, int h2, int h3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int hs[4] = {h0, h1, h2, h3};
+    const int HT = HP / 16, KS = HP / 4, K0 = OP / 4;
+    int off = 0, poff = 0, last = O;
+    double v = 0.;
+    bool found = false;
+    for (int l = 0; l < n_hidden && !found; ++l) {
+        const int ks = (l == 0) ? K0 : KS, h = hs[l];
+        const int nfrag = HT * ks * 64;
+        if (idx < off + nfrag) {
+            const int f = (idx - off) >> 6, lane = (idx - off) & 63;
+            const int t = f / ks, s = f % ks;
+            const int row = 16 * t + (lane & 15), col = 4 * s + (lane >> 4);
+            v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
+            found = true;
+        } else if (idx < off + nfrag + HP) {
+            const int j = idx - off - nfrag;
+            v = (j < h) ? params[poff + h * last + j] : 0.;
+            found = true;
+        }
+        off += nfrag + HP;
+        poff += h * last + h;
+        last = h;
+    }
+    if (!found) {
+        const int j = idx - off;
+        if (j < A * HP) {
+            const int r = j / HP, m = j % HP;
+            v = (m < last) ? params[poff + r * last + m] : 0.;
+        } else {
+            const int r = j - A * HP;
+            v = (r < A) ? params[poff + A * last + r] : 0.;
+        }
+    }
+    out[idx] = v;
+}
+
+// The fused wrappers of a rollout: every op known and used once, sizes in range.  Yields the policy's input dimension.
+static inline int check_wrap(psh_ctx* c, const psh_wrappers& w, int O, int* obs_dim, bool* has_delay) {
+    *obs_dim = O;
+    *has_delay = false;
+    if (w.n_ops < 0 || w.n_ops > PSH_MAX_WRAP) { set_err(c, "wrap.n_ops outside 0..PSH_MAX_WRAP"); return PSH_ERR_ARG; }
+    unsigned seen = 0;
+    for (int j = 0; j < w.n_ops; ++j) {
+        const int op = w.ops[j];
+        if (op < PSH_WRAP_ACT_NORM || op > PSH_WRAP_OBS_PARTIAL) { set_err(c, "unknown wrapper op"); return PSH_ERR_ARG; }
+        if (seen & (1u << op)) { set_err(c, "each wrapper kind can be fused once"); return PSH_ERR_UNSUPPORTED; }
+        seen |= 1u << op;
+        if (op == PSH_WRAP_ACT_DELAY) {
+            *has_delay = true;
+            if (w.act_delay_row < 0 && (w.act_delay < 0 || w.act_delay > PSH_MAX_DELAY)) {
+                set_err(c, "act_delay outside 0..PSH_MAX_DELAY");
+                return PSH_ERR_ARG;
+            }
+        }
+        if (op == PSH_WRAP_OBS_PARTIAL) {
+            const int m = w.obs_keep_mask;
+            if (m <= 0 || m >= (1 << O)) {
+                if (m != (1 << O) - 1) { set_err(c, "obs_keep_mask must select 1..O observations"); return PSH_ERR_ARG; }
+            }
+            *obs_dim = __builtin_popcount((unsigned)m);
+        }
+    }
+    return PSH_OK;
+}
+
+// Persistent launch of a rollout kernel: grid from the occupancy query, the ActDelay ring buffers sized to it.
+template <class K>
+static inline int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_bytes, RolloutArgs& a, int act_dim, bool need_delay_q,
+                             hipStream_t st) {
+    if (lds_bytes)
+        PSH_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, a.n_envs);
+    a.n_lanes = (long)grid * block;
+    if (need_delay_q) {
+        const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes);
+        if (rc != PSH_OK) return rc;
+        a.delay_q = c->delay_q;
+    }
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, st, a);
+    PSH_HIP(c, hipGetLastError());
+    if (c->timed) PSH_HIP(c, hipEventRecord(c->ev1, st));
+    return PSH_OK;
+}
+
+template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, RolloutArgs& a, hipStream_t st) {
+    using E = Env<KIND>;
+    const psh_policy& p = d->policy;
+    const bool per_env = p.policy_index != nullptr && p.n_policies > 1;
+    int Oe = E::O;
+    bool has_delay = false;
+    {
+        const int rc = check_wrap(c, d->wrap, E::O, &Oe, &has_delay);
+        if (rc != PSH_OK) return rc;
+    }
+    if (p.expl_kind < PSH_EXPL_NONE || p.expl_kind > PSH_EXPL_UNIFORM) { set_err(c, "unknown exploration kind"); return PSH_ERR_ARG; }
+    const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE;  // both live in the WRAP kernels
+    a.obs_dim = Oe;
+    if (p.kind == PSH_POL_LINEAR) {
+        if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }
+        int F = 0;
+        for (int f = 0; f < p.n_feats; ++f) {
+            if (p.feats[f] < 0 || p.feats[f] > PSH_FEAT_SINCOS) { set_err(c, "unknown feature id"); return PSH_ERR_ARG; }
+            F += (p.feats[f] == PSH_FEAT_CONST) ? 1 : Oe;
+        }
+        if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
+        a.num_feat = F;
+        if (per_env)
+            return wrapped ? launch_persistent(c, k_rollout_linear<KIND, true, true>, 256, 0, a, E::A, has_delay, st)
+                           : launch_persistent(c, k_rollout_linear<KIND, true, false>, 256, 0, a, E::A, false, st);
+        return wrapped ? launch_persistent(c, k_rollout_linear<KIND, false, true>, 256, 0, a, E::A, has_delay, st)
+                       : launch_persistent(c, k_rollout_linear<KIND, false, false>, 256, 0, a, E::A, false, st);
+    }
+    if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
+    if (p.n_hidden < 1 || p.n_hidden > PSH_MAX_HIDDEN) { set_err(c, "FNNPolicy needs 1..4 hidden layers"); return PSH_ERR_ARG; }
+    int hmax = 0, np = 0, last = Oe;
+    for (int l = 0; l < p.n_hidden; ++l) {
+        const int h = p.hidden[l];
+        if (h < 1 || h > PSH_MAX_WIDTH) { set_err(c, "hidden sizes must be within 1..64"); return PSH_ERR_ARG; }
+        if (p.hidden_nonlin[l] < 0 || p.hidden_nonlin[l] > PSH_NL_SIGMOID) { set_err(c, "unknown nonlinearity"); return PSH_ERR_ARG; }
+        hmax = h > hmax ? h : hmax;
+        np += h * last + h;
+        last = h;
+    }
+    np += E::A * last + E::A;
+    if (p.num_param != np) { set_err(c, "num_param does not match the FNNPolicy layout"); return PSH_ERR_ARG; }
+    if (per_env) { set_err(c, "per-env FNN policies are not supported yet"); return PSH_ERR_UNSUPPORTED; }
+    const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
+    const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = OP / 4;
+    const int total = HT * K0 * 64 + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
+    {
+        const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total);
+        if (rc != PSH_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, Oe, (int)E::A,
+                       HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
+    PSH_HIP(c, hipGetLastError());
+    a.wfrag = c->wfrag;
+    a.lds_doubles = total;
+    constexpr int BLOCK = 512;
+    const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;
+    const bool fine = (base_doubles + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
+    a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
+    a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
+    const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
+    if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
+#define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                       \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true>, BLOCK, lds_bytes, a, E::A, has_delay, st)     \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false>, BLOCK, lds_bytes, a, E::A, false, st))
+    if (HP == 16) return PSH_LAUNCH_FNN(16, true);
+    if (HP == 32) return PSH_LAUNCH_FNN(32, true);
+    if (fine) return PSH_LAUNCH_FNN(64, true);
+    return PSH_LAUNCH_FNN(64, false);
+#undef PSH_LAUNCH_FNN
+}
