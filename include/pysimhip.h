@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 103
+#define PSH_VERSION 104
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -141,7 +141,7 @@ typedef struct psh_policy {
     int32_t num_param;                     /* parameters per policy (checked against the layout) */
     int32_t pad_;
     const double* params;                  /* [dev] [n_policies, num_param] row-major */
-    const int32_t* policy_index;           /* [dev] [N] row of params used by env i, or NULL (row 0) */
+    const int32_t* policy_index;           /* [dev] [N] row of params used by env i, or NULL (row 0); LINEAR only */
     /* Action-noise exploration around the policy, StochasticActionExplStrat.forward
      * (Pyrado/pyrado/exploration/stochastic_action.py:42-68): the exploratory action is what the rollout records
      * and what the environment chain receives.
@@ -152,7 +152,10 @@ typedef struct psh_policy {
      * Drawn from Philox4x32-10 keyed like the wrapper noise (psh_wrappers.noise_seed / env_offset, step index),
      * on a stream of its own. */
     int32_t expl_kind;                     /* psh_expl_kind */
-    int32_t pad2_;
+    int32_t policy_group;                  /* > 0: population mode of ParameterExplorationSampler.sample
+                                              (Pyrado/pyrado/sampling/parameter_exploration_sampler.py:174-201): N =
+                                              n_policies * policy_group and env i uses row i / policy_group of params
+                                              (policy_index must be NULL).  LINEAR and FNN. */
     double expl_mean[PSH_MAX_ACT];
     double expl_scale[PSH_MAX_ACT];
 } psh_policy;

@@ -643,7 +643,10 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
     for (int r = 0; r < P; ++r) dp[r] = d->domain_param[(size_t)r * d->ld_dp + col];
     for (int r = 0; r < d->init_dim; ++r) init[r] = d->init_state[(size_t)r * d->ld_init + i];
     env_reset(&e, &d->task, dp, init, d->init_dim);
-    const double* pw = d->policy.params + (size_t)(d->policy.policy_index ? d->policy.policy_index[i] : 0) * d->policy.num_param;
+    /* population mode (parameter_exploration_sampler.py:174-201): policy i / policy_group */
+    const size_t prow = d->policy.policy_index ? (size_t)d->policy.policy_index[i]
+                                                : (d->policy.policy_group > 0 ? (size_t)(i / d->policy.policy_group) : 0);
+    const double* pw = d->policy.params + prow * d->policy.num_param;
     const uint64_t genv = w->env_offset + (uint64_t)i;
 
     int delay = 0, has_delay = 0, new_array = 0;

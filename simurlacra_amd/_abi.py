@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 103
+PSH_VERSION = 104
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -57,7 +57,7 @@ class PshPolicy(C.Structure):
         ('n_hidden', C.c_int32), ('hidden', C.c_int32*PSH_MAX_HIDDEN), ('hidden_nonlin', C.c_int32*PSH_MAX_HIDDEN),
         ('out_nonlin', C.c_int32), ('n_policies', C.c_int32), ('num_param', C.c_int32), ('pad_', C.c_int32),
         ('params', C.c_void_p), ('policy_index', C.c_void_p),
-        ('expl_kind', C.c_int32), ('pad2_', C.c_int32), ('expl_mean', C.c_double*PSH_MAX_ACT), ('expl_scale', C.c_double*PSH_MAX_ACT),
+        ('expl_kind', C.c_int32), ('policy_group', C.c_int32), ('expl_mean', C.c_double*PSH_MAX_ACT), ('expl_scale', C.c_double*PSH_MAX_ACT),
     ]
 
 

@@ -51,10 +51,10 @@ static inline int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t 
 
 // Persistent launch: as many workgroups as the device keeps resident (lanes pull envs from the queue), fewer when the
 // batch is smaller than that.
-template <class K> static unsigned persistent_grid(psh_ctx* c, K kernel, int block, size_t lds_bytes, int n_envs) {
+template <class K> static unsigned persistent_grid(psh_ctx* c, K kernel, int block, size_t lds_bytes, long n_envs) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     const long resident = (long)per_cu * c->num_cus;
-    const long need = ((long)n_envs + block - 1) / block;
+    const long need = (n_envs + block - 1) / block;
     return (unsigned)(need < resident ? need : resident);
 }

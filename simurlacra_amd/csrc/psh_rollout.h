@@ -123,6 +123,30 @@ template <int KIND, bool WRAP> struct Lane {
         }
     }
 
+    // Population mode of the FNN kernel: the 16 lanes of an MFMA tile must share one policy, so work is handed out per
+    // tile.  Task q = (policy q / chunks, rollouts 16 (q % chunks) ... of that policy); a tile takes the next task
+    // when none of its lanes has an env.  Returns the policy of this lane's tile.
+    PSH_DEV int turnover_tile(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol) {
+        if (i >= 0 && !live) { store(a, wrap); i = -1; }
+        const int lane = threadIdx.x & 63;
+        const unsigned long long busy = __ballot(i >= 0);
+        const bool tile_free = ((busy >> (lane & 48)) & 0xFFFFull) == 0;
+        if (tile_free && !exhausted) {
+            const int R = a.pol.policy_group, chunks = (R + 15) / 16;
+            unsigned int q = 0;
+            if ((lane & 15) == 0) q = atomicAdd(a.queue, 1u);
+            q = __shfl(q, lane & 48);
+            if (q < (unsigned int)(a.pol.n_policies * chunks)) {
+                pol = (int)(q / chunks);
+                const int r = 16 * (int)(q % chunks) + (lane & 15);
+                if (r < R) { i = (long)pol * R + r; load(a, task, wrap); }
+            } else {
+                exhausted = true;
+            }
+        }
+        return pol;
+    }
+
     PSH_DEV void load(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
         const long col = a.dp_index ? (long)a.dp_index[i] : i;
         const DpCol p{a.domain_param, a.ld_dp, col};
@@ -308,7 +332,8 @@ template <int KIND, bool WRAP> struct Lane {
 };
 
 // ------------------------------------------------------------------------------------- LinearPolicy rollouts
-// PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] of params.
+// PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] (or, in
+// population mode, row i / policy_group) of params.
 template <int KIND, bool PER_ENV, bool WRAP>
 __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
@@ -335,7 +360,9 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         if (L.i < 0) continue;
         if (PER_ENV && w_env != L.i) {
-            w = a.pol.params + (long)(a.pol.policy_index ? a.pol.policy_index[L.i] : 0) * a.pol.num_param;
+            const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
+                                                : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
+            w = a.pol.params + row * a.pol.num_param;
             w_env = L.i;
         }
         double obs[E::O], act[E::A];
@@ -410,7 +437,7 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
     }
 }
 
-template <int KIND, int HP, bool FINE, bool WRAP>
+template <int KIND, int HP, bool FINE, bool WRAP, bool POP>
 __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
@@ -418,14 +445,17 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     double* const w_lds = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    double* const stage = lds + a.lds_doubles + wave * (OP * 64);
-    double* const tanh_tab = lds + a.lds_doubles + 8 * (OP * 64);
+    // POP (population mode): every tile reads the weight image of its own policy from global memory (the images of
+    // a population do not fit into LDS; they stay resident in L2 / Infinity Cache), LDS holds no weights
+    const int w_doubles = POP ? 0 : a.lds_doubles;
+    double* const stage = lds + w_doubles + wave * (OP * 64);
+    double* const tanh_tab = lds + w_doubles + 8 * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
     const double* const task_base = opaque_lds_base(task_lds);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
     const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
 
-    for (int j = threadIdx.x; j < a.lds_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    for (int j = threadIdx.x; j < w_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
     for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
     stage_task(a, task_lds);
     __syncthreads();
@@ -434,8 +464,9 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     L.init();
 
     const int n_hidden = a.pol.n_hidden;
+    int pol = 0;  // POP: policy of this lane's tile
     for (;;) {
-        L.turnover(a, task, wrap);
+        if constexpr (POP) pol = L.turnover_tile(a, task, wrap, pol); else L.turnover(a, task, wrap);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         double obs[OP], act[E::A];
 #pragma unroll
@@ -449,15 +480,23 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        const unsigned long long live_mask = __ballot(L.live);
         for (int tile = 0; tile < 4; ++tile) {
+            const double* wimg;  // weight image of this tile's policy
+            if constexpr (POP) {
+                if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;  // nobody in this tile needs an action
+                wimg = a.wfrag + (long)__builtin_amdgcn_readlane(pol, 16 * tile) * a.lds_doubles;
+            } else {
+                wimg = w_lds;
+            }
             double y[KS];
             // layer 0
             {
                 double xin[K0];
 #pragma unroll
                 for (int s = 0; s < K0; ++s) xin[s] = stage[(4 * s + q) * 64 + 16 * tile + c];
-                const double* wl = w_lds;
-                const double* bl = w_lds + HT * K0 * 64;
+                const double* wl = wimg;
+                const double* bl = wimg + HT * K0 * 64;
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
                     v4d acc;
@@ -477,7 +516,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 double x[KS];
 #pragma unroll
                 for (int m = 0; m < KS; ++m) x[m] = y[m];
-                const double* wl = w_lds + off;
+                const double* wl = wimg + off;
                 const double* bl = wl + HT * KS * 64;
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
@@ -494,7 +533,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
-            const double* wo = w_lds + off;
+            const double* wo = wimg + off;
 #pragma unroll
             for (int r = 0; r < E::A; ++r) {
                 double p = 0.;
@@ -514,9 +553,11 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
 template <int KIND>
 __global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict__ out, int total, int O, int A, int HP,
-                           int OP, int n_hidden, int h0, int h1, int h2, int h3) {
+                           int OP, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    params += (long)blockIdx.y * num_param;  // one image per policy (blockIdx.y)
+    out += (long)blockIdx.y * total;
     const int hs[4] = {h0, h1, h2, h3};
     const int HT = HP / 16, KS = HP / 4, K0 = OP / 4;
     int off = 0, poff = 0, last = O;
@@ -585,10 +626,10 @@ static inline int check_wrap(psh_ctx* c, const psh_wrappers& w, int O, int* obs_
 // Persistent launch of a rollout kernel: grid from the occupancy query, the ActDelay ring buffers sized to it.
 template <class K>
 static inline int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_bytes, RolloutArgs& a, int act_dim, bool need_delay_q,
-                             hipStream_t st) {
+                                    hipStream_t st, long work_lanes = -1) {
     if (lds_bytes)
         PSH_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, a.n_envs);
+    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, work_lanes < 0 ? (long)a.n_envs : work_lanes);
     a.n_lanes = (long)grid * block;
     if (need_delay_q) {
         const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes);
@@ -605,7 +646,12 @@ static inline int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_
 template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, RolloutArgs& a, hipStream_t st) {
     using E = Env<KIND>;
     const psh_policy& p = d->policy;
-    const bool per_env = p.policy_index != nullptr && p.n_policies > 1;
+    const bool pop = p.policy_group > 0;
+    if (pop && (p.policy_index != nullptr || (long)p.n_policies * p.policy_group != (long)d->n_envs)) {
+        set_err(c, "population mode needs policy_index == NULL and n_envs == n_policies * policy_group");
+        return PSH_ERR_ARG;
+    }
+    const bool per_env = (p.policy_index != nullptr || pop) && p.n_policies > 1;
     int Oe = E::O;
     bool has_delay = false;
     {
@@ -643,20 +689,37 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     }
     np += E::A * last + E::A;
     if (p.num_param != np) { set_err(c, "num_param does not match the FNNPolicy layout"); return PSH_ERR_ARG; }
-    if (per_env) { set_err(c, "per-env FNN policies are not supported yet"); return PSH_ERR_UNSUPPORTED; }
+    if (per_env && !pop) {
+        set_err(c, "FNN policies per environment need population mode (policy_group): the 16 environments of an MFMA tile share one policy");
+        return PSH_ERR_UNSUPPORTED;
+    }
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
     const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = OP / 4;
     const int total = HT * K0 * 64 + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
     {
-        const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total);
+        const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total * (per_env ? p.n_policies : 1));
         if (rc != PSH_OK) return rc;
     }
-    hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256), dim3(256), 0, st, p.params, c->wfrag, total, Oe, (int)E::A,
-                       HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3]);
+    hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256, per_env ? p.n_policies : 1), dim3(256), 0, st, p.params,
+                       c->wfrag, total, Oe, (int)E::A, HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
+                       p.num_param);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
     a.lds_doubles = total;
     constexpr int BLOCK = 512;
+    if (per_env) {  // population: weights stay in global memory, work is handed out per 16-lane tile
+        a.tanh_tab = c->tanh_tab;
+        a.tanh_n = PSH_TANH8_N;
+        const size_t lds_pop = ((size_t)(BLOCK / 64) * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
+        const long lanes = (long)p.n_policies * ((p.policy_group + 15) / 16) * 16;
+#define PSH_LAUNCH_POP(HP_)                                                                                              \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, true>, BLOCK, lds_pop, a, E::A, has_delay, st, lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true>, BLOCK, lds_pop, a, E::A, false, st, lanes))
+        if (HP == 16) return PSH_LAUNCH_POP(16);
+        if (HP == 32) return PSH_LAUNCH_POP(32);
+        return PSH_LAUNCH_POP(64);
+#undef PSH_LAUNCH_POP
+    }
     const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;
     const bool fine = (base_doubles + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
     a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
@@ -664,8 +727,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
     if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
 #define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                       \
-    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true>, BLOCK, lds_bytes, a, E::A, has_delay, st)     \
-             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false>, BLOCK, lds_bytes, a, E::A, false, st))
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false>, BLOCK, lds_bytes, a, E::A, has_delay, st) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false>, BLOCK, lds_bytes, a, E::A, false, st))
     if (HP == 16) return PSH_LAUNCH_FNN(16, true);
     if (HP == 32) return PSH_LAUNCH_FNN(32, true);
     if (fine) return PSH_LAUNCH_FNN(64, true);

@@ -93,12 +93,13 @@ class Engine:
 
     # -- fused rollouts
     def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *,
-                flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, record=False, wrap=None,
-                final_state=True, out=None):
+                flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, policy_group=0, record=False,
+                wrap=None, final_state=True, out=None):
         """ N fused rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]
         (device tensors, fp64).  Returns a dict of device tensors: ret [N], length [N], status [N], final_state [S, N]
         and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N].  `wrap` (a WrapSpec) fuses environment
-        wrappers into the step loop; with an ObsPartialWrapper in it O is the number of kept observations. """
+        wrappers into the step loop; with an ObsPartialWrapper in it O is the number of kept observations.
+        policy_group = R > 0: population mode, env i runs params[i // R] (N = n_policies * R). """
         S, O, A, P, _ = abi.ENV_DIMS[env_kind]
         O_rec = O if wrap is None else wrap.obs_dim(O)
         init_state, domain_param = self.f64(init_state), self.f64(domain_param)
@@ -125,7 +126,7 @@ class Engine:
         if wrap is not None:
             d.wrap = wrap.to_c(O, A)
         d.task = task_c
-        d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index))
+        d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group)
         d.ret, d.length, d.status = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status'])
         d.final_state = _ptr(out.get('final_state'))
         d.obs, d.act, d.rew = _ptr(out.get('obs')), _ptr(out.get('act')), _ptr(out.get('rew'))

@@ -171,7 +171,7 @@ def sample_init_states(plan: EnvPlan, eng, n: int, dp, dp_index, seed: int, env_
 
 
 def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_steps=None, stop_on_done=True,
-              record=True, params=None, policy_index=None, noise_seed=0, env_offset=0):
+              record=True, params=None, policy_index=None, policy_group=0, noise_seed=0, env_offset=0):
     """ N rollouts on the device.  Fused kernel when the policy allows it (the wrappers of the env chain are fused
     with it), else a step loop with the policy evaluated by torch on the whole batch.  Returns the dict of device
     tensors of Engine.rollout. """
@@ -189,7 +189,8 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
         if params is None:
             params = policy.fused_params().detach().to(torch.float64)
         return eng.rollout(plan.kind, plan.sim.dt, T, task_c, spec, params, init_state, dp, flags=plan.flags(stop_on_done),
-                           dp_index=dp_index, policy_index=policy_index, record=record, wrap=wrap)
+                           dp_index=dp_index, policy_index=policy_index, policy_group=policy_group, record=record,
+                           wrap=wrap)
     if params is not None:
         raise NotImplementedError('per-environment policy parameters need a fusable policy')
     return _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap)

@@ -100,21 +100,15 @@ class ParameterExplorationSampler:
         lanes = my*R
         dev = eng.device
         r_idx = to.arange(R, dtype=to.int32, device=dev).repeat(my)
-        p_idx = to.arange(my, dtype=to.int32, device=dev).repeat_interleave(R)
         init = init_r[:, r_idx.long()].contiguous()
         spec = self.policy.fused_spec() if hasattr(self.policy, 'fused_spec') else None
         if spec is None:
             raise NotImplementedError('ParameterExplorationSampler needs a LinearPolicy or FNNPolicy that the rollout '
                                       'kernels can fuse')
         my_params = param_sets[p0:p1].to(dev)
-        if spec.kind == 'linear' or my == 1:
-            out = run_batch(plan, eng, self.policy, init, dp, r_idx, record=self.record_trajectories, params=my_params,
-                            policy_index=p_idx if my > 1 else None, noise_seed=key, env_offset=p0*R)
-        else:
-            # FNN populations: one launch per parameter set, each over the R shared pairs
-            outs = [run_batch(plan, eng, self.policy, init_r, dp, None, record=self.record_trajectories,
-                              params=my_params[j], noise_seed=key, env_offset=(p0 + j)*R) for j in range(my)]
-            out = {k: to.cat([o[k] for o in outs], dim=-1) for k in outs[0]}
+        # one launch for the whole population: lane j*R + r runs parameter set j on the shared pair r
+        out = run_batch(plan, eng, self.policy, init, dp, r_idx, record=self.record_trajectories, params=my_params,
+                        policy_group=R if my > 1 else 0, noise_seed=key, env_offset=p0*R)
         batch = RolloutBatch(plan, out, dp, r_idx)
         batch.check()
         means = eng.segment_mean(out['ret'], R) if lanes > 0 else to.empty(0, dtype=to.float64, device=dev)

@@ -96,7 +96,7 @@ class PolicySpec:
             last = h
         return n + self.act_dim*last + self.act_dim
 
-    def to_c(self, n_policies: int = 1, params_ptr: int = 0, index_ptr: int = 0) -> abi.PshPolicy:
+    def to_c(self, n_policies: int = 1, params_ptr: int = 0, index_ptr: int = 0, policy_group: int = 0) -> abi.PshPolicy:
         p = abi.PshPolicy()
         if self.kind == 'linear':
             p.kind = abi.POL_LINEAR
@@ -130,6 +130,7 @@ class PolicySpec:
             for i in range(self.act_dim):
                 p.expl_mean[i], p.expl_scale[i] = mean[i], scale[i]
         p.n_policies = int(n_policies)
+        p.policy_group = int(policy_group)
         p.num_param = self.num_param
         p.params = params_ptr
         p.policy_index = index_ptr

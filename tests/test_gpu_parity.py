@@ -238,6 +238,44 @@ def test_buffer_mode_and_population_mode(eng, orc):
         assert cases.rel_err(out[k].cpu().numpy(), ref[k]) <= TOL, k
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+@pytest.mark.parametrize('R', [1, 8, 16, 20])
+def test_population_mode(eng, orc, policy, R):
+    """ ParameterExplorationSampler's layout: env j*R + r runs parameter set j.  For FNN policies the 16 environments
+    of an MFMA tile share a policy, so the kernel hands out work per tile: R below, at and above the tile size. """
+    kind, pop = abi.ENV_QCP_ST, 37
+    kw = dict(hidden=(64, 32)) if policy == 'fnn' else {}
+    case = cases.make_case(kind, pop*R, seed=13, policy=policy, **kw)
+    params = 0.5*np.random.default_rng(2).standard_normal((pop, case['ps'].num_param))
+    kwr = dict(policy_group=R, record=True)
+    ref = orc.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], params, case['init'], case['dp'], **kwr)
+    out = eng.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], params, case['init'], case['dp'], **kwr)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    for k in ('obs', 'act', 'rew', 'ret', 'final_state'):
+        assert cases.rel_err(out[k].cpu().numpy(), ref[k]) <= TOL, k
+    # and with wrappers plus exploration noise behind the policy
+    import dataclasses
+    ps = dataclasses.replace(case['ps'], expl_kind='normal', expl_scale=[0.2])
+    wrap = cases.WrapSpec(ops=['act_delay', 'act_norm'], act_delay=1, noise_seed=4)
+    kwr = dict(policy_group=R, wrap=wrap)
+    ref = orc.rollout(kind, case['dt'], 40, case['task_c'], ps, params, case['init'], case['dp'], **kwr)
+    out = eng.rollout(kind, case['dt'], 40, case['task_c'], ps, params, case['init'], case['dp'], **kwr)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+
+
+def test_large_fnn_population(eng, orc):
+    """ more tile tasks than resident tiles: tiles take over new (policy, chunk) tasks """
+    kind, pop, R = abi.ENV_OMO, 3000, 4
+    case = cases.make_case(kind, pop*R, seed=3, policy='fnn', hidden=(16,))
+    params = 0.5*np.random.default_rng(5).standard_normal((pop, case['ps'].num_param))
+    ref = orc.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, case['init'], case['dp'], policy_group=R)
+    out = eng.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, case['init'], case['dp'], policy_group=R)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+
+
 def test_ragged_and_empty_batches(eng, orc):
     """ N not a multiple of the wave/block size, N = 1 and N = 0 """
     kind = abi.ENV_QQ
