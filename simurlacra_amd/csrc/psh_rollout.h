@@ -523,9 +523,20 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                     v4d acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+                    if constexpr (POP) {
+                        // weights come from global memory here: all fragments of this output row are requested
+                        // before the first MFMA, so their latency is paid once per row instead of once per fragment
+                        double af[KS];
 #pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
+                        for (int s = 0; s < KS; ++s) af[s] = wl[(t * KS + s) * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], x[s], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
