@@ -1,10 +1,10 @@
 // libpysimhip.so — kernels and C ABI (include/pysimhip.h) of the MI355X batched rollout engine.
 //
 // Kernels (all gfx950, wave64):
-//   k_rollout_linear<KIND, PER_ENV, WRAP>  fused reset + T x (LinearPolicy forward, SimPyEnv.step); one lane per env;
+//   k_rollout_linear<KIND, PER_ENV, WRAP>  (psh_rollout.h) fused reset + T x (LinearPolicy forward, SimPyEnv.step); one lane per env;
 //                                    WRAP adds the fused environment wrappers (action/observation normalisation,
 //                                    delay, noise, partial observation)
-//   k_rollout_fnn<KIND, HP, FINE, WRAP>  same with an FNNPolicy: the hidden layers run on v_mfma_f64_16x16x4_f64 with
+//   k_rollout_fnn<KIND, HP, FINE, WRAP, POP>  (psh_rollout.h) same with an FNNPolicy: the hidden layers run on v_mfma_f64_16x16x4_f64 with
 //                                    the weights as the A operand and 16 environments as the columns of B, so a
 //                                    layer's accumulator is directly the next layer's B operand
 //   k_reset / k_step                 SimPyEnv.reset / SimPyEnv.step for caller-supplied actions
