@@ -115,7 +115,14 @@ template <int KIND, bool WRAP> struct Lane {
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
     // an env has no influence on its results.
-    PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+    // BATCH > 1: the exchange is deferred until BATCH lanes of the wave wait for it (or none is running any more).
+    // Storing and loading an env costs about as much as one step of a LinearPolicy rollout and the whole wave pays
+    // for it whenever a single lane needs it; with short episodes that is most steps.
+    template <int BATCH = 1> PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+        if (BATCH > 1) {
+            const bool want = (i >= 0 && !live) || (i < 0 && !exhausted);
+            if (__popcll(__ballot(want)) < BATCH && __any(live)) return;
+        }
         if (i >= 0 && !live) { store(a, wrap); i = -1; }
         if (i < 0 && !exhausted) {
             const unsigned int nxt = atomicAdd(a.queue, 1u);
@@ -356,9 +363,9 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
     long w_env = -1;
     for (;;) {
         asm volatile("" ::: "memory");  // keep the LDS constants out of registers across iterations
-        L.turnover(a, task, wrap);
+        L.template turnover<8>(a, task, wrap);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
-        if (L.i < 0) continue;
+        if (L.i < 0 || !L.live) continue;
         if (PER_ENV && w_env != L.i) {
             const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
                                                 : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
