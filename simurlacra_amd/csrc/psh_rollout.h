@@ -489,9 +489,11 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 
         const unsigned long long live_mask = __ballot(L.live);
         for (int tile = 0; tile < 4; ++tile) {
+            // nobody in this tile needs an action: skip it (the drain at the end of a launch, when few long episodes
+            // are left, then costs a quarter per step; partially filled population tiles)
+            if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;
             const double* wimg;  // weight image of this tile's policy
             if constexpr (POP) {
-                if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;  // nobody in this tile needs an action
                 wimg = a.wfrag + (long)__builtin_amdgcn_readlane(pol, 16 * tile) * a.lds_doubles;
             } else {
                 wimg = w_lds;
