@@ -432,6 +432,40 @@ def test_step_sequence_basics():
         StepSequence(rewards=rew, actions=act)
 
 
+def test_structured_features():
+    """ MultFeat / RandFourierFeat / RBFFeat (Pyrado/pyrado/policies/features.py:143-303): sizes, values, and a
+    LinearPolicy on top of them (not fusable: evaluated by torch in the batched step loop) """
+    from simurlacra_amd.policies import MultFeat, RandFourierFeat, RBFFeat
+    x = to.tensor([0.5, -2., 3.], dtype=to.float64)
+    xb = to.stack([x, 2*x])
+    mf = MultFeat([0, 2])
+    assert mf(x).tolist() == [1.5] and mf(xb).shape == (2, 1) and mf(xb)[1, 0] == 6.
+    with pytest.raises(pyrado.ShapeErr):
+        MultFeat([1])
+    to.manual_seed(0)
+    rff = RandFourierFeat(inp_dim=3, num_feat_per_dim=7, bandwidth=np.array([1., 2., 4.]))
+    ref = np.sqrt(2/7.)*np.cos(rff.freq.numpy() @ x.numpy() + rff.shift.numpy())
+    np.testing.assert_allclose(rff(x).numpy(), ref, rtol=1e-12)
+    assert rff(xb).shape == (2, 7)
+    rbf = RBFFeat(num_feat_per_dim=5, bounds=(np.array([-1., -3., 0.]), np.array([1., 3., 4.])))
+    v = rbf(x)
+    assert v.shape == (15,) and np.allclose(v.reshape(3, 5).sum(dim=1).numpy(), 1.)
+    c0 = np.linspace(-1, 1, 5)
+    e0 = np.exp(np.log(0.2)/0.25*(0.5 - c0)**2)
+    np.testing.assert_allclose(v[:5].numpy(), e0/e0.sum(), rtol=1e-12)
+    joint = RBFFeat(num_feat_per_dim=5, bounds=(np.array([-1., -3., 0.]), np.array([1., 3., 4.])), state_wise_norm=False)
+    assert joint(xb).shape == (2, 15) and np.allclose(joint(xb).sum(dim=1).numpy(), 1.)
+    with pytest.raises(pyrado.ValueErr):
+        RBFFeat(num_feat_per_dim=1, bounds=(np.zeros(2), np.ones(2)))
+    stack = FeatureStack([const_feat, identity_feat, mf, rff, rbf])
+    assert stack.get_num_feat(3) == 1 + 3 + 1 + 7 + 15 and stack(x).shape == (27,) and stack(xb).shape == (2, 27)
+    assert stack.fused_names() is None
+    env = QQubeSim(dt=0.004, max_steps=10)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat, RBFFeat(3, env.obs_space.bounds)]))
+    assert pol.num_param == 6 + 18 and pol.fused_spec() is None
+    assert pol(to.zeros(6, dtype=to.float64)).shape == (1,) and pol(to.zeros(4, 6, dtype=to.float64)).shape == (4, 1)
+
+
 # ------------------------------------------------------------------------------------------ return statistics
 @pytest.mark.parametrize('epsilon', [1, 0.5, 0.1])
 @pytest.mark.parametrize('num_ro', [10, 20])
