@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 104
+#define PSH_VERSION 105
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -170,6 +170,7 @@ typedef struct psh_policy {
 #define PSH_ST_NAN 1      /* NaN in observation, action or state: the reference raises ValueErr */
 #define PSH_ST_FAILED 2   /* state left the (inclusive) state-space box: task.has_failed        */
 #define PSH_ST_TIMEOUT 4  /* curr_step reached max_steps                                        */
+#define PSH_ST_BERNOULLI 8 /* rollout ended by the stochastic reset (bernoulli_reset)           */
 
 /* Environment wrappers fused into the rollout (Pyrado/pyrado/environment_wrappers/): what EnvWrapperAct.step
  * and EnvWrapperObs.reset/step (base.py:145-231) do around the simulation each step.  `ops` lists the wrappers
@@ -259,6 +260,8 @@ typedef struct psh_rollout_desc {
     psh_task task;
     psh_policy policy;
     psh_wrappers wrap;          /* [host] fused environment wrappers; all-zero = none */
+    double bernoulli_reset;     /* rollout(bernoulli_reset=p), sampling/rollout.py:248-254: after every step the rollout
+                                   ends with probability p (0 = off); drawn from the Philox stream of wrap.noise_seed */
     /* outputs, all [dev]; ret/length/status are mandatory, the rest may be NULL */
     double* ret;          /* [N]   undiscounted return = sum of rewards (step_sequence.py:626-635) */
     int32_t* length;      /* [N]   number of executed steps (rollout length) */

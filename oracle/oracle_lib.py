@@ -60,7 +60,8 @@ def _f64(a):
 
 
 def rollout(env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *, flags=abi.F_STOP_ON_DONE,
-            dp_index=None, policy_index=None, policy_group=0, record=False, wrap=None, n_threads=0):
+            dp_index=None, policy_index=None, policy_group=0, record=False, wrap=None, bernoulli_reset=0.,
+            n_threads=0):
     """ N rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]. """
     S, O, A, P, _ = abi.ENV_DIMS[env_kind]
     O_rec = O if wrap is None else wrap.obs_dim(O)
@@ -79,6 +80,7 @@ def rollout(env_kind, dt, max_steps, task_c, policy_spec, params, init_state, do
     d.domain_param, d.dp_index, d.ld_dp = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1]
     if wrap is not None:
         d.wrap = wrap.to_c(O, A)
+    d.bernoulli_reset = float(bernoulli_reset)
     d.task = task_c
     d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group)
     d.ret, d.length, d.status, d.final_state = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status']), _ptr(out['final_state'])

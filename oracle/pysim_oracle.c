@@ -722,6 +722,12 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
         ++k;
         wrap_obs(w, &e, genv, (uint32_t)k, sim_obs, obs);
         if (st & PSH_ST_NAN) break;
+        if (d->bernoulli_reset > 0. && !(done && stop_on_done) && e.curr_step < T) {
+            /* sampling/rollout.py:248-254: stop with probability p after the step (flagged only if nothing else ended it) */
+            double u[2];
+            step_uniforms(w->noise_seed, genv, (uint32_t)(k - 1), 4u, u);
+            if (u[0] < d->bernoulli_reset) { st |= PSH_ST_BERNOULLI; break; }
+        }
     }
     if (d->obs) for (int r = 0; r < OP; ++r) d->obs[((size_t)k * OP + r) * N + i] = obs[r];
     d->ret[i] = ret;

@@ -632,7 +632,8 @@ class NpObsPartial(NpWrapper):  # observation_partial.py:43-46
         return obs[self.keep], rew, done, info
 
 
-def rollout_np(env: NpEnv, policy, init_state, domain_param=None, stop_on_done=True, act_delay=0):
+def rollout_np(env: NpEnv, policy, init_state, domain_param=None, stop_on_done=True, act_delay=0, bernoulli_reset=None,
+               seed=0, env_id=0):
     """ sampling/rollout.py:88-275 (+ ActDelayWrapper environment_wrappers/action_delay.py:55-81) """
     obs = env.reset(init_state, domain_param)
     queue = [np.zeros(env.a_lo.shape)]*act_delay  # legacy shortcut for a single outermost ActDelayWrapper
@@ -654,6 +655,9 @@ def rollout_np(env: NpEnv, policy, init_state, domain_param=None, stop_on_done=T
         rew_hist.append(rew)
         t_hist.append(info['t'])
         obs = obs_next
+        # stochastic reset, sampling/rollout.py:248-254 (one uniform per step from the product's Philox stream 4)
+        if bernoulli_reset is not None and step_uniforms(seed, env_id, len(rew_hist) - 1, 4)[0] < bernoulli_reset:
+            break
     obs_hist.append(obs)
     return dict(observations=np.stack(obs_hist), actions=np.stack(act_hist), rewards=np.array(rew_hist),
                 t=np.array(t_hist), length=len(rew_hist), ret=float(np.sum(rew_hist)), final_state=np.array(env.state).copy())

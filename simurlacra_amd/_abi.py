@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 104
+PSH_VERSION = 105
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -27,7 +27,7 @@ FEAT_IDS = dict(const=0, identity=1, sign=2, abs=3, squared=4, cubed=5, sig=6, b
                 sincos=11)
 NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF = 1, 2, 4
-ST_NAN, ST_FAILED, ST_TIMEOUT = 1, 2, 4
+ST_NAN, ST_FAILED, ST_TIMEOUT, ST_BERNOULLI = 1, 2, 4, 8
 DISTR_CONST, DISTR_NORMAL, DISTR_UNIFORM, DISTR_BERNOULLI = range(4)
 WRAP_ACT_NORM, WRAP_ACT_DELAY, WRAP_ACT_NOISE, WRAP_OBS_NOISE, WRAP_OBS_NORM, WRAP_OBS_PARTIAL = range(1, 7)
 
@@ -78,7 +78,7 @@ class PshRolloutDesc(C.Structure):
         ('dt', C.c_double),
         ('init_state', C.c_void_p), ('init_dim', C.c_int32), ('ld_init', C.c_int32),
         ('domain_param', C.c_void_p), ('dp_index', C.c_void_p), ('ld_dp', C.c_int32), ('pad_', C.c_int32),
-        ('task', PshTask), ('policy', PshPolicy), ('wrap', PshWrappers),
+        ('task', PshTask), ('policy', PshPolicy), ('wrap', PshWrappers), ('bernoulli_reset', C.c_double),
         ('ret', C.c_void_p), ('length', C.c_void_p), ('status', C.c_void_p), ('final_state', C.c_void_p),
         ('obs', C.c_void_p), ('act', C.c_void_p), ('rew', C.c_void_p),
         ('stream', C.c_void_p),

@@ -22,6 +22,7 @@ struct RolloutArgs {
     psh_task task;
     psh_wrappers wrap;     // directly behind `task`: the two are staged into LDS as one block
     psh_policy pol;
+    double bernoulli;      // rollout(bernoulli_reset): probability of ending the rollout after a step, 0 = off
     int obs_dim;           // entries of the observation the policy sees (all, or those kept by OBS_PARTIAL)
     double* delay_q;       // ACT_DELAY: ring buffers [PSH_MAX_DELAY][A][n_lanes], one column per resident lane
     long n_lanes;
@@ -317,6 +318,13 @@ template <int KIND, bool WRAP> struct Lane {
         k += 1;
         if (st & PSH_ST_NAN) live = false;
         if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
+        if constexpr (WRAP) {
+            if (live && a.bernoulli > 0.) {  // stochastic reset (sampling/rollout.py:248-254)
+                double u0, u1;
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)(k - 1), 4u, u0, u1);
+                if (u0 < a.bernoulli) { st |= PSH_ST_BERNOULLI; live = false; }
+            }
+        }
     }
 
     PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap) {
@@ -679,7 +687,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         if (rc != PSH_OK) return rc;
     }
     if (p.expl_kind < PSH_EXPL_NONE || p.expl_kind > PSH_EXPL_UNIFORM) { set_err(c, "unknown exploration kind"); return PSH_ERR_ARG; }
-    const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE;  // both live in the WRAP kernels
+    if (!(d->bernoulli_reset >= 0. && d->bernoulli_reset <= 1.)) { set_err(c, "bernoulli_reset must be within [0, 1]"); return PSH_ERR_ARG; }
+    // wrappers, exploration noise and the stochastic reset live in the WRAP kernels
+    const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
     a.obs_dim = Oe;
     if (p.kind == PSH_POL_LINEAR) {
         if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }

@@ -358,7 +358,7 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
     a.init_state = d->init_state; a.ld_init = d->ld_init;
     a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
-    a.task = d->task; a.wrap = d->wrap; a.pol = d->policy;
+    a.task = d->task; a.wrap = d->wrap; a.pol = d->policy; a.bernoulli = d->bernoulli_reset;
     a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
     a.obs = d->obs; a.act = d->act; a.rew = d->rew;
     hipStream_t st = (hipStream_t)d->stream;

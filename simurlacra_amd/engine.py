@@ -94,7 +94,7 @@ class Engine:
     # -- fused rollouts
     def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *,
                 flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, policy_group=0, record=False,
-                wrap=None, final_state=True, out=None):
+                wrap=None, bernoulli_reset=0., final_state=True, out=None):
         """ N fused rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]
         (device tensors, fp64).  Returns a dict of device tensors: ret [N], length [N], status [N], final_state [S, N]
         and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N].  `wrap` (a WrapSpec) fuses environment
@@ -125,6 +125,7 @@ class Engine:
         d.domain_param, d.dp_index, d.ld_dp = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1]
         if wrap is not None:
             d.wrap = wrap.to_c(O, A)
+        d.bernoulli_reset = float(bernoulli_reset)
         d.task = task_c
         d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group)
         d.ret, d.length, d.status = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status'])

@@ -74,9 +74,10 @@ class EnvPlan:
 
     def wrap_spec(self, noise_seed: int = 0, env_offset: int = 0):
         """ The wrapper chain as the kernels take it (vectors indexed by the simulation's observation / action
-        index), or None for a bare simulation. """
+        index).  A bare simulation gets an empty chain that still carries the key of the noise streams (exploration
+        noise and the stochastic reset draw from them). """
         if not self.wrappers:
-            return None
+            return WrapSpec(ops=[], noise_seed=noise_seed, env_offset=env_offset)
         O = self.O
         spec = WrapSpec(ops=[op for op, _ in self.wrappers], noise_seed=noise_seed, env_offset=env_offset)
         partial = next((w for op, w in self.wrappers if op == 'obs_partial'), None)
@@ -171,7 +172,8 @@ def sample_init_states(plan: EnvPlan, eng, n: int, dp, dp_index, seed: int, env_
 
 
 def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_steps=None, stop_on_done=True,
-              record=True, params=None, policy_index=None, policy_group=0, noise_seed=0, env_offset=0):
+              record=True, params=None, policy_index=None, policy_group=0, noise_seed=0, env_offset=0,
+              bernoulli_reset=None):
     """ N rollouts on the device.  Fused kernel when the policy allows it (the wrappers of the env chain are fused
     with it), else a step loop with the policy evaluated by torch on the whole batch.  Returns the dict of device
     tensors of Engine.rollout. """
@@ -179,6 +181,9 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
     if T == inf:
         raise ValueErr(msg='batched rollouts need a finite max_steps')
     T = int(T)
+    p_reset = 0. if bernoulli_reset is None else float(bernoulli_reset)
+    if not 0. <= p_reset <= 1.:
+        raise ValueErr(given=bernoulli_reset, ge_constraint='0', le_constraint='1')
     S, A = plan.S, plan.A
     task_c = plan.sim.task_spec().to_c(S, A)
     spec = policy.fused_spec() if hasattr(policy, 'fused_spec') else None
@@ -190,10 +195,11 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
             params = policy.fused_params().detach().to(torch.float64)
         return eng.rollout(plan.kind, plan.sim.dt, T, task_c, spec, params, init_state, dp, flags=plan.flags(stop_on_done),
                            dp_index=dp_index, policy_index=policy_index, policy_group=policy_group, record=record,
-                           wrap=wrap)
+                           wrap=wrap, bernoulli_reset=p_reset)
     if params is not None:
         raise NotImplementedError('per-environment policy parameters need a fusable policy')
-    return _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap)
+    return _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap,
+                               p_reset)
 
 
 def _obs_bounds(plan, dp, dp_index, N):
@@ -217,7 +223,8 @@ def _obs_bounds(plan, dp, dp_index, N):
     return -hi, hi
 
 
-def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap=None):
+def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_done, record, task_c, wrap=None,
+                        p_reset=0.):
     """ rollout() loop (Pyrado/pyrado/sampling/rollout.py:133-254) for N envs at once with an arbitrary torch policy;
     the wrappers of the chain are applied to the whole batch between policy and psh_step.  Noise comes from torch's
     generator here (the fused kernels use their own counter-based one). """
@@ -314,6 +321,10 @@ def _run_batch_stepwise(plan, eng, policy, init_state, dp, dp_index, T, stop_on_
         obs = torch.where(stepped.unsqueeze(0), process_obs(o), obs)
         done = d.bool() & stepped
         live = stepped & ~(done & stop_on_done) & ~((st & abi.ST_NAN) != 0)
+        if p_reset > 0. and k + 1 < T:  # stochastic reset (Pyrado/pyrado/sampling/rollout.py:248-254)
+            hit = live & (torch.rand(N, dtype=torch.float64, device=dev) < p_reset)
+            out['status'] |= hit.to(torch.int32)*abi.ST_BERNOULLI
+            live = live & ~hit
         k += 1
     if record:
         idx = out['length'].long()

@@ -33,8 +33,8 @@ class ParallelSampler(SamplerBase):
     def __init__(self, env, policy, num_envs: int = 1, *, min_rollouts: int = None, min_steps: int = None,
                  bernoulli_reset: float = None, seed: int = None, record_trajectories: bool = True):
         super().__init__(min_rollouts=min_rollouts, min_steps=min_steps)
-        if bernoulli_reset is not None:
-            raise NotImplementedError('bernoulli_reset is not supported by the batched sampler')
+        if bernoulli_reset is not None and not 0. <= bernoulli_reset <= 1.:
+            raise ValueErr(given=bernoulli_reset, ge_constraint='0', le_constraint='1')
         self.env, self.policy, self.num_envs = env, policy, num_envs
         self.bernoulli_reset = bernoulli_reset
         self.record_trajectories = record_trajectories
@@ -48,6 +48,8 @@ class ParallelSampler(SamplerBase):
             self._plan = EnvPlan(env)
         if policy is not None:
             self.policy = policy
+        if bernoulli_reset is not None:
+            self.bernoulli_reset = bernoulli_reset
 
     def set_seed(self, seed: int):
         self.seed, self._calls = int(seed), 0
@@ -62,7 +64,7 @@ class ParallelSampler(SamplerBase):
         dp, dp_index = sample_domain_params(plan, eng, m, seed=key, env_offset=global_offset + start)
         init = sample_init_states(plan, eng, m, dp, dp_index, seed=key, env_offset=global_offset + start)
         out = run_batch(plan, eng, self.policy, init, dp, dp_index, record=self.record_trajectories, noise_seed=key,
-                        env_offset=global_offset + start)
+                        env_offset=global_offset + start, bernoulli_reset=self.bernoulli_reset)
         return RolloutBatch(plan, out, dp, dp_index)
 
     def sample(self) -> RolloutBatch:

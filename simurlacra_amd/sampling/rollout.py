@@ -87,15 +87,15 @@ def rollout(env: Env, policy, eval: bool = False, max_steps: int = None, reset_k
         env.max_steps = max_steps
     reset_kwargs = dict() if reset_kwargs is None else reset_kwargs
 
-    plan = _fused_plan(env, policy, bernoulli=bernoulli_reset is not None, no_reset=no_reset, dts=record_dts,
+    plan = _fused_plan(env, policy, bernoulli=False, no_reset=no_reset, dts=record_dts,
                        render=render_mode.text or render_mode.video, recurrent=getattr(policy, 'is_recurrent', False))
     if plan is not None:
-        return _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close)
+        return _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close, bernoulli_reset)
     return _rollout_stepwise(env, policy, eval, reset_kwargs, render_mode, render_step, bernoulli_reset, no_reset,
                              no_close, record_dts, stop_on_done)
 
 
-def _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close):
+def _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close, bernoulli_reset=None):
     from ..engine import get_engine
     from .batch import RolloutBatch, run_batch
     init_state = _reset_host_side(env, reset_kwargs.get('init_state'), reset_kwargs.get('domain_param'))
@@ -106,9 +106,11 @@ def _rollout_fused(env, plan, policy, eval, reset_kwargs, stop_on_done, no_close
     sim = plan.sim
     dp = eng.f64(plan.dp_column().reshape(-1, 1))
     # the noise wrappers of the reference draw from NumPy's global generator: take this rollout's key from it
-    noise_seed = int(np.random.randint(0, 2**31 - 1)) if plan.wrappers else 0
+    spec = policy.fused_spec()
+    stochastic = plan.wrappers or spec.expl_kind is not None or bernoulli_reset is not None
+    noise_seed = int(np.random.randint(0, 2**31 - 1)) if stochastic else 0
     out = run_batch(plan, eng, policy, eng.f64(init_state.reshape(-1, 1)), dp, stop_on_done=stop_on_done, record=True,
-                    noise_seed=noise_seed)
+                    noise_seed=noise_seed, bernoulli_reset=bernoulli_reset)
     batch = RolloutBatch(plan, out, dp)
     batch.check()
     ro = batch[0]

@@ -293,7 +293,10 @@ def test_exploration_strategy_runs_fused():
     pol = FNNPolicy(env.spec, [32, 32], to.tanh)
     expl = NormalActNoiseExplStrat(pol, std_init=0.7)
     assert expl.fused_spec().expl_kind == 'normal' and expl.fused_params().numel() == pol.num_param
-    ros = ParallelSampler(env, expl, 1, min_rollouts=400, seed=2).sample()
+    sampler = ParallelSampler(env, expl, 1, min_rollouts=400, seed=2)
+    ros = sampler.sample()
+    again = sampler.sample()   # every call draws fresh noise
+    assert not np.allclose(ros[0].actions[:5], again[0].actions[:5])
     obs = np.concatenate([ro.observations[:-1] for ro in ros])
     act = np.concatenate([ro.actions for ro in ros])
     with to.no_grad():
@@ -311,6 +314,29 @@ def test_exploration_strategy_runs_fused():
     with to.no_grad():
         resid = act - pol(to.as_tensor(obs)).numpy()
     assert resid.min() >= -0.5 and resid.max() <= 0.5 and abs(resid.std() - 0.5/np.sqrt(3)) < 0.02
+
+
+def test_bernoulli_reset_in_sampler_and_rollout():
+    """ ParallelSampler(bernoulli_reset=p) and rollout(bernoulli_reset=p), Pyrado/pyrado/sampling/rollout.py:248-254:
+    complete rollouts whose lengths follow a geometric law; min_steps sampling tops up with more of them. """
+    from simurlacra_amd.sampling.rollout import rollout
+    env = ENVS['omo'](200)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat]))
+    ros = ParallelSampler(env, pol, 1, min_rollouts=4000, bernoulli_reset=0.1, seed=3).sample()
+    L = ros.lengths
+    assert abs(L.mean() - 10.) < 0.6 and L.min() == 1
+    ro = ros[int(np.argmin(L))]
+    assert ro.length == L.min() and bool(ro.done[-1]) and ro.observations.shape[0] == ro.length + 1
+    ros = ParallelSampler(env, pol, 1, min_steps=5000, bernoulli_reset=0.1, seed=3).sample()
+    assert ros.num_steps >= 5000
+    lens = [rollout(env, pol, bernoulli_reset=0.2).length for _ in range(30)]
+    assert min(lens) < 200 and len(set(lens)) > 3
+    # a policy the kernels cannot fuse takes the torch step loop, same semantics
+    class Slow(to.nn.Module):
+        def forward(self, obs):
+            return -0.1*obs[..., :1]
+    ros = ParallelSampler(env, Slow(), 1, min_rollouts=2000, bernoulli_reset=0.1, seed=3).sample()
+    assert abs(ros.lengths.mean() - 10.) < 0.8
 
 
 def test_cvar_sampler_keeps_the_worst_quantile():

@@ -117,6 +117,30 @@ def test_rollout_with_action_noise_exploration(eng, orc, expl, policy):
         _compare_rollouts(eng, orc, case, T=40, wrap=wrap)
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+def test_rollout_with_bernoulli_reset(eng, orc, policy):
+    """ rollout(bernoulli_reset=p) (sampling/rollout.py:248-254): stop with probability p after each step, alone and
+    together with a wrapper chain; lanes freed early are refilled. """
+    for kind, wrap, n in ((abi.ENV_QQ, cases.WrapSpec(noise_seed=21, env_offset=9), 300),
+                          (abi.ENV_BOB, cases.WrapSpec(ops=['act_norm', 'obs_noise'], noise_seed=2, obs_noise_std=[0.01]*4), 200000)):
+        kw = dict(scale=0.3)
+        if policy == 'fnn':
+            kw['hidden'] = (16, 16)
+        case = cases.make_case(kind, n, seed=14 + kind, policy=policy, **kw)
+        if n > 1000:
+            ref = orc.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], case['params'], case['init'], case['dp'],
+                              wrap=wrap, bernoulli_reset=0.07)
+            out = eng.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], case['params'], case['init'], case['dp'],
+                              wrap=wrap, bernoulli_reset=0.07)
+            np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+            np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+            assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+        else:
+            _compare_rollouts(eng, orc, case, T=40, wrap=wrap, bernoulli_reset=0.07)
+    with pytest.raises(Exception):
+        eng.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], case['params'], case['init'], case['dp'], bernoulli_reset=1.5)
+
+
 def test_fused_delay_with_lane_refill(eng, orc):
     """ More envs than resident lanes and short episodes: lanes take over new envs, whose delay queues must start
     empty although the ring-buffer memory is reused. """

@@ -268,6 +268,32 @@ def test_c_and_numpy_agree_with_action_noise_exploration(expl):
     assert expl == 'normal' or (a.min() >= -1.5 and a.max() < 2.5)
 
 
+def test_c_and_numpy_agree_with_bernoulli_reset():
+    """ rollout(bernoulli_reset=p), sampling/rollout.py:248-254: after each step the rollout stops with probability p.
+    The lengths follow a geometric law truncated at max_steps. """
+    kind, n, T, p = abi.ENV_OMO, 6, 40, 0.1
+    case = cases.make_case(kind, n, seed=9, policy='linear', scale=0.2)
+    wrap = WrapSpec(noise_seed=5, env_offset=70)
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'], record=True,
+                      wrap=wrap, bernoulli_reset=p)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = onp.NpEnv('omo', case['dt'], T)
+        policy = onp.LinearPolicyNp(case['ps'].feats, case['params'].reshape(1, -1))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])), bernoulli_reset=p,
+                            seed=5, env_id=70 + i)
+        L = ro['length']
+        assert L == out['length'][i]
+        assert bool(out['status'][i] & abi.ST_BERNOULLI) == (L < T)
+        assert cases.rel_err(out['obs'][:L + 1, :, i], ro['observations']) < 1e-13
+    assert (out['length'] < T).any()
+    big = cases.make_case(kind, 20000, seed=1, policy='linear', scale=0.0)
+    o = orc.rollout(kind, big['dt'], 1000, big['task_c'], big['ps'], big['params'], big['init'], big['dp'],
+                    wrap=WrapSpec(noise_seed=11), bernoulli_reset=0.05, flags=0)
+    assert abs(o['length'].mean() - 20.) < 0.6          # mean of the geometric law, 1/p
+    assert abs((o['length'] == 1).mean() - 0.05) < 0.01
+
+
 def test_oracle_policy_forward_matches_torch():
     """ FNN.forward / LinearPolicy.forward against torch.nn.Linear in fp64 (policies/fnn.py:129-151) """
     import torch
