@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "psh_rollout.h"
@@ -290,13 +291,16 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     // the LDS one workgroup may claim through hipFuncAttributeMaxDynamicSharedMemorySize: all of a CU's (160 KB on gfx950)
     c->lds_per_block = prop.maxSharedMemoryPerMultiProcessor > prop.sharedMemPerBlock ? prop.maxSharedMemoryPerMultiProcessor
                                                                                       : prop.sharedMemPerBlock;
-    static double tab[PSH_TANH8_N + PSH_TANH_TAB_N];
+    constexpr size_t tab_n = PSH_TANH8_N + PSH_TANH_TAB_N;
+    std::unique_ptr<double[]> tab(new (std::nothrow) double[tab_n]);
+    if (!tab) { delete c; return PSH_ERR_ARG; }
     for (int j = 0; j < PSH_TANH8_N; ++j) tab[j] = (double)tanhl((long double)j / 256.0L);
     for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
+    const size_t tab_bytes = tab_n * sizeof(double);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, sizeof tab) != hipSuccess ||
-        hipMemcpy(c->tanh_tab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
-        delete c;
+        hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, tab_bytes) != hipSuccess ||
+        hipMemcpy(c->tanh_tab, tab.get(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        psh_destroy(c);  // releases whatever was created before the failure
         return PSH_ERR_HIP;
     }
     *out = c;
@@ -312,8 +316,8 @@ extern "C" void psh_destroy(psh_ctx* c) {
     if (c->delay_q) (void)hipFree(c->delay_q);
     if (c->queue) (void)hipFree(c->queue);
     if (c->tanh_tab) (void)hipFree(c->tanh_tab);
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
 }
 
