@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 105
+#define PSH_VERSION 106
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -39,6 +39,7 @@ extern "C" {
 #define PSH_MAX_HIDDEN 4  /* hidden layers of an FNN policy                        */
 #define PSH_MAX_WIDTH 64  /* widest hidden layer of an FNN policy                  */
 #define PSH_MAX_FEATS 8   /* feature functions in a LinearPolicy's FeatureStack    */
+#define PSH_MAX_LIN_FEAT 512 /* feature values of a LinearPolicy in total          */
 #define PSH_MAX_DISTR 32  /* distributions in one randomizer                       */
 #define PSH_MAX_DELAY 32  /* longest action delay (steps) of the fused ActDelay    */
 #define PSH_MAX_WRAP 6    /* fused environment wrappers around one simulation      */
@@ -122,7 +123,18 @@ typedef enum psh_policy_kind { PSH_POL_LINEAR = 0, PSH_POL_FNN = 1 } psh_policy_
 typedef enum psh_feat {
     PSH_FEAT_CONST = 0, PSH_FEAT_IDENTITY = 1, PSH_FEAT_SIGN = 2, PSH_FEAT_ABS = 3,
     PSH_FEAT_SQUARED = 4, PSH_FEAT_CUBED = 5, PSH_FEAT_SIG = 6, PSH_FEAT_BELL = 7,
-    PSH_FEAT_SIN = 8, PSH_FEAT_COS = 9, PSH_FEAT_SINSIN = 10, PSH_FEAT_SINCOS = 11
+    PSH_FEAT_SIN = 8, PSH_FEAT_COS = 9, PSH_FEAT_SINSIN = 10, PSH_FEAT_SINCOS = 11,
+    /* Feature objects with data of their own (Pyrado/pyrado/policies/features.py:143-303); O is the dimension of the
+     * observation the policy sees.
+     *  MULT  MultFeat(idcs) (:143-167): one value, the product of obs[idcs[..]].  feat_size = number of indices
+     *        (2..8), feat_arg = the indices, 4 bits each, first index in the lowest bits.
+     *  RFF   RandFourierFeat (:170-219): feat_size = D values scale * cos(obs . freq[j] + shift[j]).
+     *        feat_data at feat_off: scale, shift[D], freq[D, O] row-major.
+     *  RBF   RBFFeat (:222-303): feat_size = K centers per input dimension, K * O values ordered dimension by
+     *        dimension, exp(-scale[q] (obs[q] - centers[k, q])^2) divided by its L1 norm over k (feat_arg = 1,
+     *        state_wise_norm) or over all K * O values (feat_arg = 0); a norm <= 1e-8 divides by 1
+     *        (Pyrado/pyrado/utils/normalizing.py:87-105).  feat_data at feat_off: scale[O], centers[K, O] row-major. */
+    PSH_FEAT_MULT = 12, PSH_FEAT_RFF = 13, PSH_FEAT_RBF = 14
 } psh_feat;
 
 typedef enum psh_nonlin { PSH_NL_NONE = 0, PSH_NL_TANH = 1, PSH_NL_RELU = 2, PSH_NL_SIGMOID = 3 } psh_nonlin;
@@ -158,6 +170,12 @@ typedef struct psh_policy {
                                               (policy_index must be NULL).  LINEAR and FNN. */
     double expl_mean[PSH_MAX_ACT];
     double expl_scale[PSH_MAX_ACT];
+    int32_t feat_size[PSH_MAX_FEATS];      /* LINEAR: MULT / RFF / RBF, see psh_feat; 0 for the other features */
+    int32_t feat_arg[PSH_MAX_FEATS];
+    int32_t feat_off[PSH_MAX_FEATS];       /* offset (doubles) of the feature's data within feat_data */
+    int32_t feat_data_len;                 /* doubles in feat_data */
+    int32_t pad2_;
+    const double* feat_data;               /* [dev] data of the RFF / RBF features, NULL without any */
 } psh_policy;
 
 /* rollout flags */

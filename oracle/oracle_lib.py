@@ -82,7 +82,9 @@ def rollout(env_kind, dt, max_steps, task_c, policy_spec, params, init_state, do
         d.wrap = wrap.to_c(O, A)
     d.bernoulli_reset = float(bernoulli_reset)
     d.task = task_c
-    d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group)
+    feat_data = _f64(policy_spec.feat_data()) if policy_spec.kind == 'linear' else None
+    d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group,
+                                _ptr(feat_data) if feat_data is not None and feat_data.size else 0)
     d.ret, d.length, d.status, d.final_state = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status']), _ptr(out['final_state'])
     if record:
         d.obs, d.act, d.rew = _ptr(out['obs']), _ptr(out['act']), _ptr(out['rew'])
@@ -188,7 +190,8 @@ def constants(env_kind, dp):
 def policy_forward(policy_spec, params, obs):
     params, obs = _f64(params), _f64(obs)
     act = np.zeros(policy_spec.act_dim)
-    pc = policy_spec.to_c(1, _ptr(params), 0)
+    feat_data = _f64(policy_spec.feat_data()) if policy_spec.kind == 'linear' else None
+    pc = policy_spec.to_c(1, _ptr(params), 0, 0, _ptr(feat_data) if feat_data is not None and feat_data.size else 0)
     f = lambda a: a.ctypes.data_as(abi.c_double_p)
     lib().orc_policy_forward(C.byref(pc), policy_spec.obs_dim, policy_spec.act_dim, f(obs), f(act))
     return act

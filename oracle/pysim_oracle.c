@@ -465,7 +465,14 @@ static double nonlin(int k, double x) {
 
 static int num_feats(const psh_policy* pol, int O) {
     int n = 0;
-    for (int f = 0; f < pol->n_feats; ++f) n += (pol->feats[f] == PSH_FEAT_CONST) ? 1 : O;
+    for (int f = 0; f < pol->n_feats; ++f) {
+        switch (pol->feats[f]) {
+        case PSH_FEAT_CONST: case PSH_FEAT_MULT: n += 1; break;
+        case PSH_FEAT_RFF: n += pol->feat_size[f]; break;
+        case PSH_FEAT_RBF: n += pol->feat_size[f] * O; break;
+        default: n += O;
+        }
+    }
     return n;
 }
 
@@ -479,11 +486,53 @@ int orc_policy_num_param(const psh_policy* pol, int O, int A) {
 /* LinearPolicy.forward policies/linear.py:65-80 + features.py:34-42,90-140; FNN.forward policies/fnn.py:129-151 */
 static void policy_forward(const psh_policy* pol, const double* w, int O, int A, const double* obs, double* act) {
     if (pol->kind == PSH_POL_LINEAR) {
-        double f[PSH_MAX_FEATS * PSH_MAX_OBS];
+        double f[PSH_MAX_LIN_FEAT];
         int n = 0;
         for (int k = 0; k < pol->n_feats; ++k) {
             int id = pol->feats[k];
             if (id == PSH_FEAT_CONST) { f[n++] = 1.; continue; }
+            if (id == PSH_FEAT_MULT) { /* MultFeat.__call__ policies/features.py:160-167 */
+                double v = obs[pol->feat_arg[k] & 15];
+                for (int j = 1; j < pol->feat_size[k]; ++j) v = v * obs[(pol->feat_arg[k] >> (4 * j)) & 15];
+                f[n++] = v;
+                continue;
+            }
+            if (id == PSH_FEAT_RFF) { /* RandFourierFeat.__call__ policies/features.py:203-219 */
+                const int D = pol->feat_size[k];
+                const double* data = pol->feat_data + pol->feat_off[k];
+                const double scale = data[0], *shift = data + 1, *freq = data + 1 + D;
+                for (int j = 0; j < D; ++j) {
+                    double z = 0.;
+                    for (int i = 0; i < O; ++i) z += obs[i] * freq[j * O + i];
+                    f[n++] = scale * cos(z + shift[j]);
+                }
+                continue;
+            }
+            if (id == PSH_FEAT_RBF) { /* RBFFeat.__call__ policies/features.py:278-303, normalize utils/normalizing.py:87-105 */
+                const int K = pol->feat_size[k];
+                const double* scale = pol->feat_data + pol->feat_off[k], *cen = scale + O;
+                double total = 0.;
+                for (int i = 0; i < O; ++i) {
+                    double norm = 0.;
+                    for (int j = 0; j < K; ++j) {
+                        double dlt = obs[i] - cen[j * O + i];
+                        double e = exp(-scale[i] * (dlt * dlt));
+                        f[n + i * K + j] = e;
+                        norm += fabs(e);
+                    }
+                    total += norm;
+                    if (pol->feat_arg[k]) { /* every input dimension sums to one */
+                        if (!(norm > 1e-8)) norm = 1.;
+                        for (int j = 0; j < K; ++j) f[n + i * K + j] /= norm;
+                    }
+                }
+                if (!pol->feat_arg[k]) {
+                    if (!(total > 1e-8)) total = 1.;
+                    for (int j = 0; j < K * O; ++j) f[n + j] /= total;
+                }
+                n += K * O;
+                continue;
+            }
             for (int i = 0; i < O; ++i) {
                 double x = obs[i], v = x;
                 switch (id) {

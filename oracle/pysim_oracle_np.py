@@ -407,14 +407,56 @@ def feat_eval(name, x):  # policies/features.py:90-140
     }[name](x)
 
 
+class MultFeatNp:
+    """ policies/features.py:143-167 """
+
+    def __init__(self, idcs):
+        self.idcs = list(idcs)
+
+    def __call__(self, x):
+        out = x[self.idcs[0]]
+        for i in self.idcs[1:]:
+            out = out*x[i]
+        return np.array([out])
+
+
+class RandFourierFeatNp:
+    """ policies/features.py:170-219 with the sampled frequencies and shifts given """
+
+    def __init__(self, scale, freq, shift):
+        self.scale, self.freq, self.shift = float(scale), np.asarray(freq, float), np.asarray(shift, float)
+
+    def __call__(self, x):
+        return self.scale*np.cos(x @ self.freq.T + self.shift)
+
+
+class RBFFeatNp:
+    """ policies/features.py:222-303; normalize() of utils/normalizing.py:87-105 """
+
+    def __init__(self, centers, scale, state_wise=True):
+        self.centers, self.scale, self.state_wise = np.asarray(centers, float), scale, state_wise
+
+    @staticmethod
+    def _normalize(x, axis):
+        norm = np.atleast_1d(np.linalg.norm(x, ord=1, axis=axis))
+        norm = np.where(norm > 1e-8, norm, np.ones_like(norm))
+        return x/np.expand_dims(norm, axis)
+
+    def __call__(self, x):
+        sample = np.exp(-self.scale*np.power(np.tile(x, (self.centers.shape[0], 1)) - self.centers, 2))   # [K, dim]
+        if self.state_wise:
+            return self._normalize(sample, 0).T.reshape(-1)
+        return self._normalize(sample.T.reshape(-1), -1).reshape(-1)
+
+
 class LinearPolicyNp:
-    """ policies/linear.py:65-80 """
+    """ policies/linear.py:65-80; `feats` holds names of the element-wise features or feature objects """
 
     def __init__(self, feats, W):
         self.feats, self.W = feats, np.asarray(W, dtype=np.float64)
 
     def __call__(self, obs):
-        parts = [np.ones(1) if f == 'const' else feat_eval(f, obs) for f in self.feats]
+        parts = [np.ones(1) if f == 'const' else (feat_eval(f, obs) if isinstance(f, str) else f(obs)) for f in self.feats]
         return self.W.dot(np.concatenate(parts))
 
 

@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 105
+PSH_VERSION = 106
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -12,6 +12,7 @@ PSH_MAX_DP = 20
 PSH_MAX_HIDDEN = 4
 PSH_MAX_WIDTH = 64
 PSH_MAX_FEATS = 8
+PSH_MAX_LIN_FEAT = 512
 PSH_MAX_DISTR = 32
 PSH_MAX_DELAY = 32
 PSH_MAX_WRAP = 6
@@ -24,7 +25,7 @@ FIN_ENABLED, FIN_ALWAYS_POSITIVE, FIN_ALWAYS_NEGATIVE, FIN_STATE_DEPENDENT, FIN_
 POL_LINEAR, POL_FNN = 0, 1
 EXPL_NONE, EXPL_NORMAL, EXPL_UNIFORM = 0, 1, 2
 FEAT_IDS = dict(const=0, identity=1, sign=2, abs=3, squared=4, cubed=5, sig=6, bell=7, sin=8, cos=9, sinsin=10,
-                sincos=11)
+                sincos=11, mult=12, rff=13, rbf=14)
 NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF = 1, 2, 4
 ST_NAN, ST_FAILED, ST_TIMEOUT, ST_BERNOULLI = 1, 2, 4, 8
@@ -58,6 +59,8 @@ class PshPolicy(C.Structure):
         ('out_nonlin', C.c_int32), ('n_policies', C.c_int32), ('num_param', C.c_int32), ('pad_', C.c_int32),
         ('params', C.c_void_p), ('policy_index', C.c_void_p),
         ('expl_kind', C.c_int32), ('policy_group', C.c_int32), ('expl_mean', C.c_double*PSH_MAX_ACT), ('expl_scale', C.c_double*PSH_MAX_ACT),
+        ('feat_size', C.c_int32*PSH_MAX_FEATS), ('feat_arg', C.c_int32*PSH_MAX_FEATS), ('feat_off', C.c_int32*PSH_MAX_FEATS),
+        ('feat_data_len', C.c_int32), ('pad2_', C.c_int32), ('feat_data', C.c_void_p),
     ]
 
 

@@ -68,6 +68,14 @@ PSH_DEV double nl_apply(int nl, double v) {
     }
 }
 
+// p * v[idx] for a register-resident array.  Written as a chain of products so that the array is never indexed
+// dynamically (a select between its elements gets turned into a select between addresses of a scratch copy).
+template <int N> PSH_DEV double times_element(double p, const double* v, int idx) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) p = (idx == q) ? p * v[q] : p;
+    return p;
+}
+
 PSH_DEV double feat_apply(int id, double x) {
     switch (id) {
     case PSH_FEAT_SIGN: return (double)((x > 0.) - (x < 0.));
@@ -352,7 +360,7 @@ template <int KIND, bool WRAP> struct Lane {
 template <int KIND, bool PER_ENV, bool WRAP>
 __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
-    constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_FEATS * PSH_MAX_OBS;
+    constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_LIN_FEAT;
     __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
     double* const lds_w = lds_lin;
     const double* const task_base = opaque_lds_base(lds_lin + W_DOUBLES);
@@ -392,6 +400,69 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n];
                 n += 1;
+            } else if (id == PSH_FEAT_MULT) {  // MultFeat (policies/features.py:143-167)
+                const int arg = a.pol.feat_arg[f];
+                double v = 1.0;  // 1 * x is exact
+                for (int j = 0; j < a.pol.feat_size[f]; ++j) v = times_element<E::O>(v, obs, (arg >> (4 * j)) & 15);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n] * v;
+                n += 1;
+            } else if (id == PSH_FEAT_RFF) {  // RandFourierFeat (policies/features.py:203-219)
+                const int D = a.pol.feat_size[f];
+                const double* data = a.pol.feat_data + a.pol.feat_off[f];  // wave-uniform: scalar loads
+                const double scale = data[0];
+                const double* shift = data + 1;
+                const double* freq = data + 1 + D;
+                for (int j = 0; j < D; ++j) {
+                    double z = 0.;
+#pragma unroll
+                    for (int q = 0; q < E::O; ++q)
+                        if (!WRAP || q < Oe) z = fma(obs[q], freq[j * Oe + q], z);
+                    double sn, cs;
+                    psh_sincos(z + shift[j], &sn, &cs);
+                    const double v = scale * cs;
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + j] * v;
+                }
+                n += D;
+            } else if (id == PSH_FEAT_RBF) {  // RBFFeat (policies/features.py:278-303)
+                // sum_k w_k e_k / norm instead of sum_k w_k (e_k / norm): the activations need not be kept
+                const int K = a.pol.feat_size[f];
+                const bool state_wise = a.pol.feat_arg[f] != 0;
+                const double* scale = a.pol.feat_data + a.pol.feat_off[f];
+                const double* cen = scale + Oe;
+                double total = 0., joint[E::A];
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) joint[r] = 0.;
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) {
+                    if (WRAP && q >= Oe) break;
+                    double norm = 0., acc[E::A];
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) acc[r] = 0.;
+                    for (int j = 0; j < K; ++j) {
+                        const double dl = obs[q] - cen[j * Oe + q];
+                        const double e = psh_exp(-scale[q] * (dl * dl));
+                        norm += e;
+#pragma unroll
+                        for (int r = 0; r < E::A; ++r) acc[r] += w[r * F + n + q * K + j] * e;
+                    }
+                    if (state_wise) {
+                        norm = (norm > 1e-8) ? norm : 1.;  // normalize() of utils/normalizing.py:87-105
+#pragma unroll
+                        for (int r = 0; r < E::A; ++r) act[r] += acc[r] / norm;
+                    } else {
+                        total += norm;
+#pragma unroll
+                        for (int r = 0; r < E::A; ++r) joint[r] += acc[r];
+                    }
+                }
+                if (!state_wise) {
+                    total = (total > 1e-8) ? total : 1.;
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act[r] += joint[r] / total;
+                }
+                n += K * Oe;
             } else {
 #pragma unroll
                 for (int q = 0; q < E::O; ++q) {
@@ -695,8 +766,30 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }
         int F = 0;
         for (int f = 0; f < p.n_feats; ++f) {
-            if (p.feats[f] < 0 || p.feats[f] > PSH_FEAT_SINCOS) { set_err(c, "unknown feature id"); return PSH_ERR_ARG; }
-            F += (p.feats[f] == PSH_FEAT_CONST) ? 1 : Oe;
+            const int id = p.feats[f], sz = p.feat_size[f];
+            if (id < 0 || id > PSH_FEAT_RBF) { set_err(c, "unknown feature id"); return PSH_ERR_ARG; }
+            long data = 0;  // doubles the feature reads from feat_data
+            if (id == PSH_FEAT_MULT) {
+                if (sz < 2 || sz > 8) { set_err(c, "MultFeat takes 2..8 indices"); return PSH_ERR_ARG; }
+                for (int j = 0; j < sz; ++j)
+                    if (((p.feat_arg[f] >> (4 * j)) & 15) >= Oe) { set_err(c, "MultFeat index outside the observation"); return PSH_ERR_ARG; }
+                F += 1;
+            } else if (id == PSH_FEAT_RFF) {
+                if (sz < 1 || sz > PSH_MAX_LIN_FEAT) { set_err(c, "RandFourierFeat needs 1..512 features"); return PSH_ERR_ARG; }
+                data = 1 + (long)sz + (long)sz * Oe;
+                F += sz;
+            } else if (id == PSH_FEAT_RBF) {
+                if (sz < 2 || sz > PSH_MAX_LIN_FEAT) { set_err(c, "RBFFeat needs 2..512 centers per dimension"); return PSH_ERR_ARG; }
+                data = (long)Oe + (long)sz * Oe;
+                F += sz * Oe;
+            } else {
+                F += (id == PSH_FEAT_CONST) ? 1 : Oe;
+            }
+            if (data > 0 && (!p.feat_data || p.feat_off[f] < 0 || (long)p.feat_off[f] + data > (long)p.feat_data_len)) {
+                set_err(c, "feat_data does not hold the data of a RandFourierFeat / RBFFeat");
+                return PSH_ERR_ARG;
+            }
+            if (F > PSH_MAX_LIN_FEAT) { set_err(c, "LinearPolicy with more than 512 feature values"); return PSH_ERR_ARG; }
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;

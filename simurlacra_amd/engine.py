@@ -127,7 +127,10 @@ class Engine:
             d.wrap = wrap.to_c(O, A)
         d.bernoulli_reset = float(bernoulli_reset)
         d.task = task_c
-        d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group)
+        # data of RandFourierFeat / RBFFeat: freed after the launch, which the caching allocator orders on this stream
+        feat_data = policy_spec.feat_data() if policy_spec.kind == 'linear' else None
+        feat_data = self.f64(feat_data) if feat_data is not None and feat_data.size else None
+        d.policy = policy_spec.to_c(params.shape[0], _ptr(params), _ptr(policy_index), policy_group, _ptr(feat_data))
         d.ret, d.length, d.status = _ptr(out['ret']), _ptr(out['length']), _ptr(out['status'])
         d.final_state = _ptr(out.get('final_state'))
         d.obs, d.act, d.rew = _ptr(out.get('obs')), _ptr(out.get('act')), _ptr(out.get('rew'))

@@ -78,6 +78,11 @@ class MultFeat:
             out = out*inp[..., i]
         return out.unsqueeze(-1)
 
+    def fused_spec(self):
+        from ..specs import FeatSpec
+        ok = 2 <= len(self._idcs) <= 8 and all(0 <= int(i) < 8 for i in self._idcs)
+        return FeatSpec('mult', idcs=[int(i) for i in self._idcs]) if ok else None
+
 
 class RandFourierFeat:
     """ Random Fourier features of a Gaussian kernel, scale*cos(inp @ freq^T + shift)
@@ -98,6 +103,11 @@ class RandFourierFeat:
         batched = inp.ndimension() == 2
         out = self.scale*to.cos(to.atleast_2d(inp).to(to.float64)@self.freq.t() + self.shift)
         return out if batched else out.squeeze(0)   # 1-dim in, 1-dim out, so that it stacks with the other features
+
+    def fused_spec(self):
+        from ..specs import FeatSpec
+        return FeatSpec('rff', scale=float(self.scale), freq=self.freq.detach().cpu().numpy(),
+                        shift=self.shift.detach().cpu().numpy())
 
 
 class RBFFeat:
@@ -145,6 +155,11 @@ class RBFFeat:
         out = self._normalized(self._exp_sq_dist(inp))
         return out if batched else out.squeeze(0)
 
+    def fused_spec(self):
+        from ..specs import FeatSpec
+        scale = self.scale.detach().cpu().numpy() if isinstance(self.scale, to.Tensor) else float(self.scale)
+        return FeatSpec('rbf', centers=self.centers.detach().cpu().numpy(), scale=scale, state_wise=self._state_wise_norm)
+
     def _normalized(self, e: to.Tensor) -> to.Tensor:
         if self._state_wise_norm:
             # every input dimension's activations sum to one; values ordered dimension by dimension
@@ -174,6 +189,7 @@ class FeatureStack:
         return sum(1 if f is const_feat else getattr(f, 'num_feat', inp_flat_dim) for f in self.feat_fcns)
 
     def fused_names(self):
-        """ Kernel names of the features in stack order, or None if one of them is not fusable. """
-        names = [FUSABLE_FEATS.get(f) for f in self.feat_fcns]
+        """ The features in stack order as the kernels take them (names of the element-wise functions, FeatSpecs of
+        the feature objects), or None if one of them cannot be fused. """
+        names = [f.fused_spec() if hasattr(f, 'fused_spec') else FUSABLE_FEATS.get(f) for f in self.feat_fcns]
         return None if any(n is None for n in names) else names

@@ -49,4 +49,9 @@ class LinearPolicy(Policy):
         names = self._feats.fused_names()
         if names is None or not 1 <= len(names) <= 8:
             return None
-        return PolicySpec('linear', self._num_obs, self._num_act, feats=names)
+        spec = PolicySpec('linear', self._num_obs, self._num_act, feats=names)
+        try:
+            spec.to_c()   # sizes the kernels do not take (too many feature values, mismatching dimensions)
+        except ValueError:
+            return None
+        return spec

@@ -69,11 +69,57 @@ class TaskSpec:
 
 
 @dataclass
+class FeatSpec:
+    """ A feature object of the LinearPolicy with data of its own (Pyrado/pyrado/policies/features.py:143-303).
+    kind 'mult': idcs.  kind 'rff': scale, freq [D, O], shift [D].  kind 'rbf': centers [K, O], scale (scalar or [O]),
+    state_wise. """
+    kind: str
+    idcs: Optional[Sequence[int]] = None
+    scale: Optional[object] = None
+    freq: Optional[np.ndarray] = None
+    shift: Optional[np.ndarray] = None
+    centers: Optional[np.ndarray] = None
+    state_wise: bool = True
+
+    def num_feat(self, obs_dim: int) -> int:
+        return {'mult': 1, 'rff': self.size(), 'rbf': self.size()*obs_dim}[self.kind]
+
+    def size(self) -> int:
+        if self.kind == 'mult':
+            return len(self.idcs)
+        return int(np.asarray(self.freq if self.kind == 'rff' else self.centers).shape[0])
+
+    def arg(self) -> int:
+        if self.kind == 'mult':
+            if not 2 <= len(self.idcs) <= 8 or any(not 0 <= int(i) < abi.PSH_MAX_OBS for i in self.idcs):
+                raise ValueError(f'a fused MultFeat takes 2..8 indices below {abi.PSH_MAX_OBS}')
+            return sum(int(i) << (4*j) for j, i in enumerate(self.idcs))
+        return int(bool(self.state_wise)) if self.kind == 'rbf' else 0
+
+    def data(self, obs_dim: int) -> np.ndarray:
+        if self.kind == 'mult':
+            return np.zeros(0)
+        if self.kind == 'rff':
+            freq = np.asarray(self.freq, dtype=np.float64)
+            shift = np.asarray(self.shift, dtype=np.float64).reshape(-1)
+            if freq.ndim != 2 or freq.shape[1] != obs_dim or shift.size != freq.shape[0]:
+                raise ValueError(f'RandFourierFeat: freq must be [D, {obs_dim}] and shift [D]')
+            return np.concatenate([[float(self.scale)], shift, freq.reshape(-1)])
+        centers = np.asarray(self.centers, dtype=np.float64)
+        if centers.ndim != 2 or centers.shape[1] != obs_dim:
+            raise ValueError(f'RBFFeat: centers must be [K, {obs_dim}]')
+        scale = np.broadcast_to(np.asarray(self.scale, dtype=np.float64).reshape(-1), (obs_dim,))
+        return np.concatenate([scale, centers.reshape(-1)])
+
+
+@dataclass
 class PolicySpec:
     kind: str                                   # 'linear' | 'fnn'
     obs_dim: int
     act_dim: int
-    feats: Sequence[str] = field(default_factory=list)     # linear: feature names in FeatureStack order
+    # linear: the FeatureStack in order.  A name for const / element-wise features, or a FeatSpec for MultFeat,
+    # RandFourierFeat, RBFFeat
+    feats: Sequence = field(default_factory=list)
     hidden: Sequence[int] = field(default_factory=list)    # fnn: hidden sizes
     hidden_nonlin: Sequence[Optional[str]] = field(default_factory=list)
     out_nonlin: Optional[str] = None
@@ -84,7 +130,13 @@ class PolicySpec:
 
     @property
     def num_feat(self) -> int:
-        return sum(1 if f == 'const' else self.obs_dim for f in self.feats)
+        return sum(f.num_feat(self.obs_dim) if isinstance(f, FeatSpec) else (1 if f == 'const' else self.obs_dim)
+                   for f in self.feats)
+
+    def feat_data(self) -> np.ndarray:
+        """ The data of the RFF / RBF features, concatenated in stack order (psh_policy.feat_data). """
+        parts = [f.data(self.obs_dim) for f in self.feats if isinstance(f, FeatSpec)]
+        return np.concatenate(parts) if parts else np.zeros(0)
 
     @property
     def num_param(self) -> int:
@@ -96,15 +148,26 @@ class PolicySpec:
             last = h
         return n + self.act_dim*last + self.act_dim
 
-    def to_c(self, n_policies: int = 1, params_ptr: int = 0, index_ptr: int = 0, policy_group: int = 0) -> abi.PshPolicy:
+    def to_c(self, n_policies: int = 1, params_ptr: int = 0, index_ptr: int = 0, policy_group: int = 0,
+             feat_data_ptr: int = 0) -> abi.PshPolicy:
         p = abi.PshPolicy()
         if self.kind == 'linear':
             p.kind = abi.POL_LINEAR
             if not 1 <= len(self.feats) <= abi.PSH_MAX_FEATS:
                 raise ValueError(f'a fused LinearPolicy takes 1..{abi.PSH_MAX_FEATS} feature functions')
+            if self.num_feat > abi.PSH_MAX_LIN_FEAT:
+                raise ValueError(f'a fused LinearPolicy takes at most {abi.PSH_MAX_LIN_FEAT} feature values')
             p.n_feats = len(self.feats)
+            off = 0
             for i, f in enumerate(self.feats):
-                p.feats[i] = abi.FEAT_IDS[f]
+                if isinstance(f, FeatSpec):
+                    p.feats[i] = abi.FEAT_IDS[f.kind]
+                    p.feat_size[i], p.feat_arg[i], p.feat_off[i] = f.size(), f.arg(), off
+                    off += f.data(self.obs_dim).size
+                else:
+                    p.feats[i] = abi.FEAT_IDS[f]
+            p.feat_data_len = off
+            p.feat_data = feat_data_ptr if off else 0
         elif self.kind == 'fnn':
             p.kind = abi.POL_FNN
             if not 1 <= len(self.hidden) <= abi.PSH_MAX_HIDDEN:

@@ -58,6 +58,35 @@ def linear_policy(kind, rng, feats=('const', 'identity', 'squared'), scale=0.5, 
     return ps, scale*rng.standard_normal(ps.num_param)
 
 
+def structured_feats(O, rng, state_wise=True, D=24, K=5):
+    """ A FeatureStack with MultFeat, RandFourierFeat and RBFFeat as FeatSpecs (data as their constructors compute it,
+    Pyrado/pyrado/policies/features.py:146-154,192-201,262-276). """
+    from simurlacra_amd.specs import FeatSpec
+    freq = rng.standard_normal((D, O))*np.sqrt(2./np.full((1, O), 2.0))
+    centers = np.stack([np.linspace(-1.5, 1.5 + 0.1*q, K) for q in range(O)], axis=1)
+    delta = centers[1] - centers[0]
+    return ['const', FeatSpec('mult', idcs=[0, O - 1]), FeatSpec('mult', idcs=[1, 1, 0]),
+            FeatSpec('rff', scale=np.sqrt(2./D), freq=freq, shift=2*np.pi*rng.random(D)), 'identity',
+            FeatSpec('rbf', centers=centers, scale=-np.log(0.2)/delta**2, state_wise=state_wise)]
+
+
+def structured_feats_np(feats):
+    """ The same stack as objects of the NumPy restatement. """
+    from oracle import pysim_oracle_np as onp
+    from simurlacra_amd.specs import FeatSpec
+    out = []
+    for f in feats:
+        if not isinstance(f, FeatSpec):
+            out.append(f)
+        elif f.kind == 'mult':
+            out.append(onp.MultFeatNp(f.idcs))
+        elif f.kind == 'rff':
+            out.append(onp.RandFourierFeatNp(f.scale, f.freq, f.shift))
+        else:
+            out.append(onp.RBFFeatNp(f.centers, f.scale, f.state_wise))
+    return out
+
+
 def fnn_policy(kind, rng, hidden=(16, 16), nonlin='tanh', out_nonlin=None, scale=0.5, obs_dim=None):
     S, O, A, P, _ = abi.ENV_DIMS[kind]
     ps = PolicySpec('fnn', O if obs_dim is None else obs_dim, A, hidden=list(hidden), hidden_nonlin=[nonlin]*len(hidden), out_nonlin=out_nonlin)

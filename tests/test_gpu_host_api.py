@@ -284,6 +284,30 @@ def test_non_fusable_policy_with_wrappers_matches_the_fused_path():
     assert cases.rel_err(a[3].actions, b[3].actions) <= TOL and cases.rel_err(a[3].observations, b[3].observations) <= TOL
 
 
+def test_linear_policy_with_feature_objects_fused_equals_torch():
+    """ LinearPolicy over MultFeat / RandFourierFeat / RBFFeat (Pyrado/pyrado/policies/features.py:143-303): the fused
+    kernel against the same policy evaluated by torch in the batched step loop """
+    from simurlacra_amd.policies import MultFeat, RandFourierFeat, RBFFeat
+    to.manual_seed(1)
+    env = ENVS['qq'](40)
+    bounds = (np.array([-1., -1., -1., -1., -30., -40.]), np.array([1., 1., 1., 1., 30., 40.]))
+    for state_wise in (True, False):
+        stack = FeatureStack([const_feat, MultFeat([0, 2]), RandFourierFeat(6, 20, bandwidth=np.full(6, 2.)), identity_feat,
+                              RBFFeat(4, bounds, state_wise_norm=state_wise)])
+        fus = LinearPolicy(env.spec, stack)
+        fus.param_values = 0.3*to.randn(fus.num_param, dtype=to.float64)
+        assert fus.fused_spec() is not None
+
+        class Opaque(to.nn.Module):
+            def forward(self, obs):
+                return fus(obs.to(to.float64))
+        a = ParallelSampler(env, fus, 1, min_rollouts=64, seed=5).sample()
+        b = ParallelSampler(env, Opaque(), 1, min_rollouts=64, seed=5).sample()
+        np.testing.assert_array_equal(a.lengths, b.lengths)
+        assert cases.rel_err(a[7].actions, b[7].actions) <= TOL and cases.rel_err(a[7].observations, b[7].observations) <= TOL
+        assert cases.rel_err(a.undiscounted_returns(), b.undiscounted_returns()) <= TOL
+
+
 def test_exploration_strategy_runs_fused():
     """ rollouts of NormalActNoiseExplStrat(policy) through the fused kernel: actions scatter around the policy's output
     with the strategy's std (Pyrado/pyrado/exploration/stochastic_action.py:96-136), trajectories are complete, and

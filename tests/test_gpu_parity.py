@@ -141,6 +141,32 @@ def test_rollout_with_bernoulli_reset(eng, orc, policy):
         eng.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], case['params'], case['init'], case['dp'], bernoulli_reset=1.5)
 
 
+@pytest.mark.parametrize('mode', ['shared', 'population', 'wrapped'])
+def test_rollout_with_structured_features(eng, orc, mode):
+    """ MultFeat, RandFourierFeat, RBFFeat (policies/features.py:143-303) evaluated inside the LinearPolicy kernel: one
+    weight set in LDS, a population of weight sets in global memory, and behind an ObsPartialWrapper. """
+    kind = abi.ENV_QQ
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    wrap = cases.WrapSpec(ops=['obs_partial', 'act_norm'], obs_keep=[1, 1, 1, 1, 0, 1]) if mode == 'wrapped' else None
+    Oe = O if wrap is None else wrap.obs_dim(O)
+    for state_wise in (True, False):
+        feats = cases.structured_feats(Oe, np.random.default_rng(8), state_wise)
+        n, R = (320, 16) if mode == 'population' else (300, 0)
+        case = cases.make_case(kind, n, seed=3, policy='linear', feats=feats, scale=0.3, obs_dim=Oe)
+        if mode == 'population':
+            case['params'] = 0.3*np.random.default_rng(4).standard_normal((n//R, case['ps'].num_param))
+        kw = dict(policy_group=R) if R else {}
+        if wrap is not None:
+            kw['wrap'] = wrap
+        _compare_rollouts(eng, orc, case, T=40, **kw)
+    # descriptors the library must reject
+    import dataclasses
+    from simurlacra_amd.specs import FeatSpec
+    bad = dataclasses.replace(case['ps'], feats=[FeatSpec('mult', idcs=[0, 7])])   # QQube observes 6 values
+    with pytest.raises(Exception):
+        eng.rollout(kind, case['dt'], 5, case['task_c'], bad, np.zeros(1), case['init'], case['dp'])
+
+
 def test_fused_delay_with_lane_refill(eng, orc):
     """ More envs than resident lanes and short episodes: lanes take over new envs, whose delay queues must start
     empty although the ring-buffer memory is reused. """

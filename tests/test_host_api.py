@@ -434,7 +434,7 @@ def test_step_sequence_basics():
 
 def test_structured_features():
     """ MultFeat / RandFourierFeat / RBFFeat (Pyrado/pyrado/policies/features.py:143-303): sizes, values, and a
-    LinearPolicy on top of them (not fusable: evaluated by torch in the batched step loop) """
+    LinearPolicy on top of them, which the kernels take as FeatSpecs with the features' data """
     from simurlacra_amd.policies import MultFeat, RandFourierFeat, RBFFeat
     x = to.tensor([0.5, -2., 3.], dtype=to.float64)
     xb = to.stack([x, 2*x])
@@ -459,10 +459,18 @@ def test_structured_features():
         RBFFeat(num_feat_per_dim=1, bounds=(np.zeros(2), np.ones(2)))
     stack = FeatureStack([const_feat, identity_feat, mf, rff, rbf])
     assert stack.get_num_feat(3) == 1 + 3 + 1 + 7 + 15 and stack(x).shape == (27,) and stack(xb).shape == (2, 27)
-    assert stack.fused_names() is None
+    names = stack.fused_names()
+    assert names[:2] == ['const', 'identity'] and [f.kind for f in names[2:]] == ['mult', 'rff', 'rbf']
     env = QQubeSim(dt=0.004, max_steps=10)
     pol = LinearPolicy(env.spec, FeatureStack([identity_feat, RBFFeat(3, env.obs_space.bounds)]))
-    assert pol.num_param == 6 + 18 and pol.fused_spec() is None
+    spec = pol.fused_spec()
+    assert pol.num_param == 6 + 18 and spec.num_param == 24 and spec.feat_data().size == 6 + 18
+    pc = spec.to_c(feat_data_ptr=1)
+    assert list(pc.feats)[:2] == [1, 14] and pc.feat_size[1] == 3 and pc.feat_arg[1] == 1 and pc.feat_data_len == 24
+    # what the kernels do not take stays with the torch step loop
+    assert LinearPolicy(env.spec, FeatureStack([RBFFeat(100, env.obs_space.bounds)])).fused_spec() is None       # 600 values
+    assert LinearPolicy(env.spec, FeatureStack([RandFourierFeat(5, 10, 1.)])).fused_spec() is None               # 5 != 6 inputs
+    assert LinearPolicy(env.spec, FeatureStack([lambda x: x])).fused_spec() is None
     assert pol(to.zeros(6, dtype=to.float64)).shape == (1,) and pol(to.zeros(4, 6, dtype=to.float64)).shape == (4, 1)
 
 

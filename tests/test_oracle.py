@@ -294,6 +294,32 @@ def test_c_and_numpy_agree_with_bernoulli_reset():
     assert abs((o['length'] == 1).mean() - 0.05) < 0.01
 
 
+@pytest.mark.parametrize('state_wise', [True, False])
+def test_c_and_numpy_agree_on_structured_features(state_wise):
+    """ MultFeat, RandFourierFeat, RBFFeat (policies/features.py:143-303) inside a LinearPolicy: the C restatement
+    against the NumPy one, which follows the reference's tensor expressions. """
+    kind, n, T = abi.ENV_QQ, 4, 40
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    rng = np.random.default_rng(3)
+    feats = cases.structured_feats(O, rng, state_wise)
+    case = cases.make_case(kind, n, seed=12, policy='linear', feats=feats, scale=0.3)
+    ps = case['ps']
+    assert ps.num_feat == 1 + 1 + 1 + 24 + O + 5*O and ps.num_param == A*ps.num_feat
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], ps, case['params'], case['init'], case['dp'], record=True)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = onp.NpEnv('qq', case['dt'], T)
+        policy = onp.LinearPolicyNp(cases.structured_feats_np(feats), case['params'].reshape(A, -1))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['act'][:L, :, i], ro['actions']) < 1e-12
+        assert cases.rel_err(out['obs'][:L + 1, :, i], ro['observations']) < 1e-12
+    # far from every center the activations underflow: the norm falls below 1e-8 and the division is by one
+    rbf = onp.RBFFeatNp(np.linspace(-1, 1, 4).reshape(4, 1), 50., True)
+    assert np.all(rbf(np.array([30.])) == 0.)
+
+
 def test_oracle_policy_forward_matches_torch():
     """ FNN.forward / LinearPolicy.forward against torch.nn.Linear in fp64 (policies/fnn.py:129-151) """
     import torch
