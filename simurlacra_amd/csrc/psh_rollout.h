@@ -467,7 +467,11 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 #pragma unroll
                 for (int q = 0; q < E::O; ++q) {
                     if (WRAP && q >= Oe) break;
-                    const double v = feat_apply(id, obs[q]);
+                    // opaque per iteration: otherwise every feature function of every observation is loop-invariant
+                    // in f and gets hoisted in front of the loop, i.e. evaluated on every step whatever the stack holds
+                    double x = obs[q];
+                    asm volatile("" : "+v"(x));
+                    const double v = feat_apply(id, x);
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * v;
                 }
