@@ -8,10 +8,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-enum { M_MFMA = 0, M_FMA, M_PHASED, M_INTERLEAVED, M_RCP, M_LDEXP, M_RNDNE, M_CVT, M_MUL, M_ADD, M_CNDMASK, M_DSREAD, M_COUNT };
+enum { M_MFMA = 0, M_FMA, M_PHASED, M_INTERLEAVED, M_RCP, M_LDEXP, M_RNDNE, M_CVT, M_MUL, M_ADD, M_CNDMASK, M_DSREAD, M_FMA_DEP, M_SELECT64, M_DIV, M_AND, M_MIN64, M_CMP64, M_SELECT32, M_MAX3, M_IDX_FP, M_IDX_INT, M_COUNT };
 static const char* names[] = {"mfma x64 (4 chains)", "fma_f64 x1024 (16 chains)", "phased 64 mfma + 1024 fma",
                               "interleaved 1 mfma : 16 fma", "rcp_f64 x256", "ldexp_f64 x256", "rndne_f64 x256",
-                              "cvt_i32_f64 x256", "mul_f64 x1024", "add_f64 x1024", "cndmask_b32 x1024", "ds_read_b64 x256"};
+                              "cvt_i32_f64 x256", "mul_f64 x1024", "add_f64 x1024", "cndmask_b32 x1024", "ds_read_b64 x256",
+                              "fma_f64 x1024 (1 dependent chain)", "cmp_gt_f64 + 2 cndmask x256", "IEEE div_f64 x256", "and_b32 x1024",
+                              "min_f64 x1024", "cmp_gt_f64 -> ballot x256", "cmp_gt_u32 + cndmask x256", "max3_u32 x1024",
+                              "tanh index, fp64 clamp x256", "tanh index, integer clamp x256"};
 
 template <int MODE> __global__ __launch_bounds__(512) void k(double* out, long long* cyc, int iters, double seed) {
     __shared__ double lds[4096];
@@ -93,6 +96,88 @@ template <int MODE> __global__ __launch_bounds__(512) void k(double* out, long l
 #pragma unroll
                 for (int t = 0; t < 16; ++t) ii[t] = (lane & (1 << (s & 3))) ? ii[t] + 1 : ii[(t + 1) & 15];
         }
+        if (MODE == M_FMA_DEP) {
+#pragma unroll
+            for (int s = 0; s < 1024; ++s) f[0] = fma(f[0], a, b);
+        }
+        if (MODE == M_SELECT64) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { f[t] = (f[t] > a) ? b : f[t]; asm volatile("" : "+v"(f[t])); }
+        }
+        if (MODE == M_DIV) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { f[t] = a / f[t]; asm volatile("" : "+v"(f[t])); }
+        }
+        if (MODE == M_AND) {
+#pragma unroll
+            for (int s = 0; s < 64; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { ii[t] = ii[t] & (lane + s); asm volatile("" : "+v"(ii[t])); }
+        }
+        if (MODE == M_MIN64) {
+#pragma unroll
+            for (int s = 0; s < 64; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { f[t] = __builtin_fmin(f[t], a); asm volatile("" : "+v"(f[t])); }
+        }
+        if (MODE == M_CMP64) {
+            unsigned long long m = 0;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { m ^= __ballot(f[t] > a + s); }
+            ii[0] += (int)m;
+        }
+        if (MODE == M_SELECT32) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { ii[t] = ((unsigned)ii[t] > (unsigned)(lane + s)) ? s : ii[t]; asm volatile("" : "+v"(ii[t])); }
+        }
+        if (MODE == M_MAX3) {
+#pragma unroll
+            for (int s = 0; s < 64; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { unsigned u = ii[t], v = ii[(t + 1) & 15], w = lane + s; u = u > v ? u : v; ii[t] = u > w ? u : w; asm volatile("" : "+v"(ii[t])); }
+        }
+        if (MODE == M_IDX_FP) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    double x = __builtin_fabs(f[t]);
+                    x = (x > 20.0) ? 20.0 : x;
+                    const double jm = x + 26388279066624.0;
+                    const double d = x - (jm - 26388279066624.0);
+                    unsigned j = (unsigned)__double2loint(jm);
+                    j = j > 5120u ? 5120u : j;
+                    ii[t] += j << 3;
+                    f[t] = d + a;
+                    asm volatile("" : "+v"(f[t]), "+v"(ii[t]));
+                }
+        }
+        if (MODE == M_IDX_INT) {
+            unsigned hm = 0;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const unsigned hi = (unsigned)__double2hiint(f[t]) & 0x7fffffffu;
+                    hm = hi > hm ? hi : hm;
+                    const unsigned hc = hi < 0x40340000u ? hi : 0x40340000u;
+                    const double x = __hiloint2double((int)hc, __double2loint(f[t]));
+                    const double jm = x + 26388279066624.0;
+                    const double d = x - (jm - 26388279066624.0);
+                    ii[t] += (unsigned)__double2loint(jm) << 3;
+                    f[t] = d + a;
+                    asm volatile("" : "+v"(f[t]), "+v"(ii[t]));
+                }
+            ii[0] += hm;
+        }
         if (MODE == M_DSREAD) {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -134,7 +219,6 @@ template <int MODE> int run(int block, int grid, int iters, double* out, long lo
 template <int MODE> int both(double* out, long long* cyc) {
     if (run<MODE>(256, 256, 2000, out, cyc)) return 1;
     if (run<MODE>(512, 256, 2000, out, cyc)) return 1;
-    if (run<MODE>(1024, 256, 2000, out, cyc)) return 1;
     return 0;
 }
 
@@ -155,5 +239,15 @@ int main() {
     rc |= both<M_ADD>(out, cyc);
     rc |= both<M_CNDMASK>(out, cyc);
     rc |= both<M_DSREAD>(out, cyc);
+    rc |= both<M_FMA_DEP>(out, cyc);
+    rc |= both<M_SELECT64>(out, cyc);
+    rc |= both<M_DIV>(out, cyc);
+    rc |= both<M_AND>(out, cyc);
+    rc |= both<M_MIN64>(out, cyc);
+    rc |= both<M_CMP64>(out, cyc);
+    rc |= both<M_SELECT32>(out, cyc);
+    rc |= both<M_MAX3>(out, cyc);
+    rc |= both<M_IDX_FP>(out, cyc);
+    rc |= both<M_IDX_INT>(out, cyc);
     return rc;
 }
