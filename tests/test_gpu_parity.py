@@ -6,7 +6,7 @@ seeded inputs.  Tolerance (floating point, stated by the task): per-step values 
 import numpy as np
 import pytest
 
-from simurlacra_amd import _abi as abi
+from simurlacra_amd import _abi as abi, envdefs
 from tests import cases
 
 pytestmark = pytest.mark.gpu
@@ -324,6 +324,37 @@ def test_large_fnn_population(eng, orc):
     out = eng.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, case['init'], case['dp'], policy_group=R)
     np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
     assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+
+
+def test_full_size_launch_is_order_invariant_and_matches_the_oracle_on_a_sample(eng, orc):
+    """ The bench's launch size (2 097 152 QQube envs, FNN 64x64, T = 600): which lane, wave or workgroup runs an env
+    must not influence its result, so a permuted launch returns the permuted results bit for bit; a sample of the
+    envs is checked against the oracle (returns and lengths; the oracle cannot run all of them in test time). """
+    import torch
+    kind, n, T = abi.ENV_QQ, 1 << 21, 600
+    rng = np.random.default_rng(17)
+    dp = cases.domain_params(kind, n, rng)
+    init = cases.init_states(kind, dp, rng)
+    ps, params = cases.fnn_policy(kind, np.random.default_rng(2), hidden=(64, 64), scale=0.25)
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    dt = cases.DT[kind]
+    dev = eng.device
+    dp_d, init_d = torch.as_tensor(dp, device=dev), torch.as_tensor(init, device=dev)
+    out = eng.rollout(kind, dt, T, task_c, ps, params, init_d, dp_d)
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    out_p = eng.rollout(kind, dt, T, task_c, ps, params, init_d[:, perm].contiguous(), dp_d[:, perm].contiguous())
+    for key in ('ret', 'length', 'status'):
+        assert torch.equal(out[key][perm], out_p[key]), key
+    assert torch.equal(out['final_state'][:, perm], out_p['final_state'])
+    assert int(out['length'].min()) >= 1 and int(out['length'].max()) <= T
+    sample = rng.choice(n, 1500, replace=False)
+    ref = orc.rollout(kind, dt, T, task_c, ps, params, init[:, sample], dp[:, sample])
+    np.testing.assert_array_equal(out['length'].cpu().numpy()[sample], ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy()[sample], ref['status'])
+    # whole rollouts of up to 600 steps: the closed loop amplifies rounding differences, so the bound on the
+    # return is looser than the per-step tolerance of the short-horizon tests
+    assert cases.rel_err(out['ret'].cpu().numpy()[sample], ref['ret']) <= 1e-6
 
 
 def test_ragged_and_empty_batches(eng, orc):
