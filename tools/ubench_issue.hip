@@ -8,13 +8,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-enum { M_MFMA = 0, M_FMA, M_PHASED, M_INTERLEAVED, M_RCP, M_LDEXP, M_RNDNE, M_CVT, M_MUL, M_ADD, M_CNDMASK, M_DSREAD, M_FMA_DEP, M_SELECT64, M_DIV, M_AND, M_MIN64, M_CMP64, M_SELECT32, M_MAX3, M_IDX_FP, M_IDX_INT, M_COUNT };
+enum { M_MFMA = 0, M_FMA, M_PHASED, M_INTERLEAVED, M_RCP, M_LDEXP, M_RNDNE, M_CVT, M_MUL, M_ADD, M_CNDMASK, M_DSREAD, M_FMA_DEP, M_SELECT64, M_DIV, M_AND, M_MIN64, M_CMP64, M_SELECT32, M_MAX3, M_IDX_FP, M_IDX_INT, M_SPLIT_HALF, M_SPLIT_PARITY, M_COUNT };
 static const char* names[] = {"mfma x64 (4 chains)", "fma_f64 x1024 (16 chains)", "phased 64 mfma + 1024 fma",
                               "interleaved 1 mfma : 16 fma", "rcp_f64 x256", "ldexp_f64 x256", "rndne_f64 x256",
                               "cvt_i32_f64 x256", "mul_f64 x1024", "add_f64 x1024", "cndmask_b32 x1024", "ds_read_b64 x256",
                               "fma_f64 x1024 (1 dependent chain)", "cmp_gt_f64 + 2 cndmask x256", "IEEE div_f64 x256", "and_b32 x1024",
                               "min_f64 x1024", "cmp_gt_f64 -> ballot x256", "cmp_gt_u32 + cndmask x256", "max3_u32 x1024",
-                              "tanh index, fp64 clamp x256", "tanh index, integer clamp x256"};
+                              "tanh index, fp64 clamp x256", "tanh index, integer clamp x256",
+                              "waves 0-3: 64 mfma, waves 4-7: 1024 fma", "even waves: 64 mfma, odd waves: 1024 fma"};
 
 template <int MODE> __global__ __launch_bounds__(512) void k(double* out, long long* cyc, int iters, double seed) {
     __shared__ double lds[4096];
@@ -178,6 +179,21 @@ template <int MODE> __global__ __launch_bounds__(512) void k(double* out, long l
                 }
             ii[0] += hm;
         }
+        if (MODE == M_SPLIT_HALF || MODE == M_SPLIT_PARITY) {
+            const int wv = threadIdx.x >> 6;
+            const bool do_mfma = MODE == M_SPLIT_HALF ? (wv < 4) : ((wv & 1) == 0);
+            if (do_mfma) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f[s], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 64; ++s)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) f[t] = fma(f[t], a, b);
+            }
+        }
         if (MODE == M_DSREAD) {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -249,5 +265,7 @@ int main() {
     rc |= both<M_MAX3>(out, cyc);
     rc |= both<M_IDX_FP>(out, cyc);
     rc |= both<M_IDX_INT>(out, cyc);
+    rc |= both<M_SPLIT_HALF>(out, cyc);
+    rc |= both<M_SPLIT_PARITY>(out, cyc);
     return rc;
 }
