@@ -485,8 +485,8 @@ class FNNPolicyNp:
 
     def __call__(self, obs):
         x = obs
-        for W, b in self.layers[:-1]:
-            x = self._nl(self.hn, W.dot(x) + b)
+        for l, (W, b) in enumerate(self.layers[:-1]):
+            x = self._nl(self.hn if isinstance(self.hn, (str, type(None))) else self.hn[l], W.dot(x) + b)
         W, b = self.layers[-1]
         return self._nl(self.on, W.dot(x) + b)
 

@@ -54,6 +54,19 @@ def test_rollout_fnn_policy(eng, orc, kind, hidden):
     _compare_rollouts(eng, orc, case, T=30 if kind == abi.ENV_QQ_ST else 50)
 
 
+@pytest.mark.parametrize('hidden_nl,out_nl', [(['relu', 'relu'], None), (['sigmoid', 'sigmoid'], None), ([None, 'tanh'], 'tanh'),
+                                              (['relu', 'sigmoid', 'tanh'], 'sigmoid'), (['tanh'], 'relu')], ids=str)
+def test_rollout_fnn_nonlinearities(eng, orc, hidden_nl, out_nl):
+    """ every hidden / output nonlinearity of FNN.forward (policies/fnn.py:129-151), mixed per layer """
+    from simurlacra_amd.specs import PolicySpec
+    for kind in (abi.ENV_QCP_SU, abi.ENV_QBB):
+        S, O, A, P, _ = abi.ENV_DIMS[kind]
+        hidden = [64, 32, 16][:len(hidden_nl)]
+        case = cases.make_case(kind, 200, seed=8 + kind, policy='fnn', hidden=hidden)
+        case['ps'] = PolicySpec('fnn', O, A, hidden=hidden, hidden_nonlin=hidden_nl, out_nonlin=out_nl)
+        _compare_rollouts(eng, orc, case, T=40)
+
+
 @pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB])
 def test_rollout_deepest_widest_fnn(eng, orc, kind):
     """ 4 hidden layers of 64: the weight image leaves no LDS for the fine tanh table, the kernel variant with the

@@ -320,6 +320,30 @@ def test_c_and_numpy_agree_on_structured_features(state_wise):
     assert np.all(rbf(np.array([30.])) == 0.)
 
 
+NONLIN_CASES = [(['relu', 'relu'], None), (['sigmoid', 'sigmoid'], None), ([None, 'tanh'], 'tanh'),
+                (['relu', 'sigmoid', 'tanh'], 'sigmoid'), (['tanh'], 'relu')]
+
+
+@pytest.mark.parametrize('hidden_nl,out_nl', NONLIN_CASES, ids=str)
+def test_c_and_numpy_agree_on_fnn_nonlinearities(hidden_nl, out_nl):
+    """ FNN.forward with every hidden / output nonlinearity the kernels know (policies/fnn.py:129-151) """
+    kind, n, T = abi.ENV_QCP_SU, 3, 40
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    hidden = [24, 16, 8][:len(hidden_nl)]
+    case = cases.make_case(kind, n, seed=5, policy='fnn', hidden=hidden)
+    ps = PolicySpec('fnn', O, A, hidden=hidden, hidden_nonlin=hidden_nl, out_nonlin=out_nl)
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], ps, case['params'], case['init'], case['dp'], record=True)
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = onp.NpEnv('qcp-su', case['dt'], T)
+        policy = onp.FNNPolicyNp(O, hidden, A, case['params'], hidden_nonlin=hidden_nl, out_nonlin=out_nl)
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['act'][:L, :, i], ro['actions']) < 1e-12
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-12
+
+
 def test_oracle_policy_forward_matches_torch():
     """ FNN.forward / LinearPolicy.forward against torch.nn.Linear in fp64 (policies/fnn.py:129-151) """
     import torch
