@@ -54,6 +54,16 @@ def test_rollout_fnn_policy(eng, orc, kind, hidden):
     _compare_rollouts(eng, orc, case, T=30 if kind == abi.ENV_QQ_ST else 50)
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+@pytest.mark.parametrize('kind,spec,np_kw', cases.custom_tasks(), ids=lambda v: cases.KIND_NAMES.get(v, '') if isinstance(v, int) else '')
+def test_rollout_with_custom_tasks(eng, orc, kind, spec, np_kw, policy):
+    """ dense cost matrices, every reward function and FinalRewMode, radial wrapping with other moduli """
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    case, T = cases.custom_task_case(kind, 300, seed=70 + kind, policy=policy)
+    case['task_c'] = spec.to_c(S, A)
+    _compare_rollouts(eng, orc, case, T=T)
+
+
 @pytest.mark.parametrize('hidden_nl,out_nl', [(['relu', 'relu'], None), (['sigmoid', 'sigmoid'], None), ([None, 'tanh'], 'tanh'),
                                               (['relu', 'sigmoid', 'tanh'], 'sigmoid'), (['tanh'], 'relu')], ids=str)
 def test_rollout_fnn_nonlinearities(eng, orc, hidden_nl, out_nl):

@@ -320,6 +320,25 @@ def test_c_and_numpy_agree_on_structured_features(state_wise):
     assert np.all(rbf(np.array([30.])) == 0.)
 
 
+@pytest.mark.parametrize('kind,spec,np_kw', cases.custom_tasks(), ids=lambda v: cases.KIND_NAMES.get(v, '') if isinstance(v, int) else '')
+def test_c_and_numpy_agree_on_custom_tasks(kind, spec, np_kw):
+    """ rewards, final rewards and radial wrapping for tasks other than the defaults; a gain high enough that a part
+    of the rollouts fails, so that the final reward is exercised """
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    n = 60
+    case, T = cases.custom_task_case(kind, n, seed=40 + kind, policy='linear')
+    out = orc.rollout(kind, case['dt'], T, spec.to_c(S, A), case['ps'], case['params'], case['init'], case['dp'], record=True)
+    assert (out['status'] & abi.ST_FAILED).any() or kind in (abi.ENV_QCP_ST, abi.ENV_QCP_SU)   # final rewards are reached
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = onp.NpEnv(cases.KIND_NAMES[kind], case['dt'], T, task=onp.Task(**np_kw))
+        policy = onp.LinearPolicyNp(case['ps'].feats, case['params'].reshape(A, -1))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-11
+
+
 NONLIN_CASES = [(['relu', 'relu'], None), (['sigmoid', 'sigmoid'], None), ([None, 'tanh'], 'tanh'),
                 (['relu', 'sigmoid', 'tanh'], 'sigmoid'), (['tanh'], 'relu')]
 
