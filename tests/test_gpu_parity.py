@@ -55,6 +55,31 @@ def test_rollout_fnn_policy(eng, orc, kind, hidden):
 
 
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
+def test_rollout_qbb_simplified_dynamics(eng, orc, policy):
+    """ QBallBalancerSim(simplified_dyn=True) (pysim/quanser_ball_balancer.py:251-252): no IK prologue, other ball model """
+    kw = dict(scale=0.3) if policy == 'linear' else dict(hidden=(32, 32), scale=0.3)
+    case = cases.make_case(abi.ENV_QBB, 300, seed=15, policy=policy, **kw)
+    _compare_rollouts(eng, orc, case, T=50, flags=abi.F_STOP_ON_DONE | abi.F_SIMPLIFIED_DYN)
+
+
+def test_step_with_infinite_horizon_flag(eng, orc):
+    """ SimPyEnv.step with max_steps = inf (pysim/base.py:179,194): stepping on past max_steps, never a time-out """
+    import torch
+    kind = abi.ENV_OMO
+    case = cases.make_case(kind, 70, seed=2, policy='linear')
+    mem_ref = orc.reset(kind, case['dt'], 5, case['task_c'], case['init'], case['dp'])
+    mem = eng.reset(kind, case['dt'], 5, case['task_c'], case['init'], case['dp'])
+    for k in range(9):
+        act = np.full((1, 70), 0.1*k)
+        o_ref, r_ref, d_ref, s_ref, _ = orc.step(kind, case['dt'], 5, case['task_c'], mem_ref, act, case['dp'], flags=abi.F_MAX_STEPS_INF)
+        o, r, d, s = eng.step(kind, case['dt'], 5, case['task_c'], mem, torch.as_tensor(act, device=eng.device), case['dp'],
+                              flags=abi.F_MAX_STEPS_INF)
+        np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+        np.testing.assert_array_equal(s.cpu().numpy(), s_ref)
+        assert not d_ref.any() and cases.rel_err(o.cpu().numpy(), o_ref) <= TOL and cases.rel_err(r.cpu().numpy(), r_ref) <= TOL
+
+
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
 @pytest.mark.parametrize('kind,spec,np_kw', cases.custom_tasks(), ids=lambda v: cases.KIND_NAMES.get(v, '') if isinstance(v, int) else '')
 def test_rollout_with_custom_tasks(eng, orc, kind, spec, np_kw, policy):
     """ dense cost matrices, every reward function and FinalRewMode, radial wrapping with other moduli """

@@ -339,6 +339,40 @@ def test_c_and_numpy_agree_on_custom_tasks(kind, spec, np_kw):
         assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-11
 
 
+def test_c_and_numpy_agree_on_simplified_qbb_dynamics_and_infinite_horizon_steps():
+    """ QBallBalancerSim(simplified_dyn=True) (pysim/quanser_ball_balancer.py:251-252) through rollouts, and
+    SimPyEnv.step with max_steps = inf (pysim/base.py:179,194): remaining_steps = 0, no time-out done. """
+    kind, n, T = abi.ENV_QBB, 4, 50
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    case = cases.make_case(kind, n, seed=61, policy='linear', scale=0.3)
+    flags = abi.F_STOP_ON_DONE | abi.F_SIMPLIFIED_DYN
+    out = orc.rollout(kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'], record=True, flags=flags)
+    full = orc.rollout(kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'], record=True)
+    assert cases.rel_err(out['obs'][:10], full['obs'][:10]) > 1e-6      # it is a different model
+    keys = list(envdefs.nominal_domain_param(kind).keys())
+    for i in range(n):
+        env = onp.NpEnv('qbb', case['dt'], T, simplified_dyn=True)
+        policy = onp.LinearPolicyNp(case['ps'].feats, case['params'].reshape(A, -1))
+        ro = onp.rollout_np(env, policy, case['init'][:, i], dict(zip(keys, case['dp'][:, i])))
+        L = ro['length']
+        assert L == out['length'][i]
+        assert cases.rel_err(out['obs'][:L + 1, :, i], ro['observations']) < 1e-12
+        assert cases.rel_err(out['rew'][:L, i], ro['rewards']) < 1e-12
+    # stepping past max_steps with the infinite-horizon flag: OMO's time-dependent final reward sees remaining = 0
+    kind = abi.ENV_OMO
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    case = cases.make_case(kind, 1, seed=2, policy='linear')
+    mem = orc.reset(kind, case['dt'], 5, case['task_c'], case['init'], case['dp'])
+    env = onp.NpEnv('omo', case['dt'], 5)
+    env.reset(case['init'][:, 0], dict(zip(envdefs.nominal_domain_param(kind).keys(), case['dp'][:, 0])))
+    for k in range(9):
+        act = np.array([[0.1*k]])
+        o, r, d, s, _ = orc.step(kind, case['dt'], 5, case['task_c'], mem, act, case['dp'], flags=abi.F_MAX_STEPS_INF)
+        o2, r2, d2, _ = env.step(act[:, 0].copy(), max_steps_inf=True)
+        assert not d[0] and not d2 and mem['curr_step'][0] == k + 1
+        assert cases.rel_err(o[:, 0], o2) < 1e-13 and abs(r[0] - r2) < 1e-13
+
+
 NONLIN_CASES = [(['relu', 'relu'], None), (['sigmoid', 'sigmoid'], None), ([None, 'tanh'], 'tanh'),
                 (['relu', 'sigmoid', 'tanh'], 'sigmoid'), (['tanh'], 'relu')]
 
