@@ -75,6 +75,13 @@ for i in range(n_np):
     tot += ro['length']
 el = time.perf_counter() - t0
 print(f'{"C1 same, NumPy restatement (1 process, reference style)":58s} {tot/el/1e3:8.3f} k env-steps/s ({n_np} rollouts)')
+# the same through a pool of worker processes, as the reference's ParallelSampler runs it; a child process of its own
+# (this one holds the GPU)
+import subprocess  # noqa: E402
+workers = 8 if quick else 16
+r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'np_pool_baseline.py'), str(workers),
+                    str(workers*(2 if quick else 10))], capture_output=True, text=True, timeout=600)
+print(f'{"C1 same, NumPy restatement in a process pool":58s} {r.stdout.strip() or r.stderr.strip()[-200:]}', flush=True)
 
 # ---- C2
 n = 1 << (16 if quick else 20)
