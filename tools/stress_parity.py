@@ -41,4 +41,34 @@ for kind in cases.KINDS:
                       f'{int((~same).sum())} envs differ in length/status; oracle self-sensitivity {sens:.2e}, '
                       f'{int((~s2).sum())} lengths', flush=True)
     print(f'{cases.KIND_NAMES[kind]:7s} done', flush=True)
+# the fused wrapper chains, exploration noise and the stochastic reset
+import copy  # noqa: E402
+import dataclasses  # noqa: E402
+for kind, wrap0 in cases.WRAP_CASES:
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    for pol in ('linear', 'fnn'):
+        for seed in range(seeds):
+            wrap = copy.deepcopy(wrap0)
+            wrap.noise_seed, wrap.env_offset = 77 + seed, 1000*seed
+            kw = dict(obs_dim=wrap.obs_dim(O), scale=0.3)
+            if pol == 'fnn':
+                kw['hidden'] = (32, 32)
+            case = cases.make_case(kind, n, seed=500*seed + kind, policy=pol, **kw)
+            dp = case['dp']
+            if wrap.act_delay_row >= 0:
+                dp = np.vstack([dp, np.random.default_rng(seed).integers(0, 6, n).astype(float)[None, :]])
+            ps = case['ps']
+            if seed % 2:
+                ps = dataclasses.replace(ps, expl_kind='normal' if seed % 4 == 1 else 'uniform', expl_mean=[0.01]*A, expl_scale=[0.2]*A)
+            args = (kind, case['dt'], T, case['task_c'], ps, case['params'], case['init'], dp)
+            kwargs = dict(record=True, wrap=wrap, bernoulli_reset=0.02 if seed % 3 == 0 else 0.)
+            ref = orc.rollout(*args, **kwargs)
+            out = {k: v.cpu().numpy() for k, v in eng.rollout(*args, **kwargs).items()}
+            same = (out['length'] == ref['length']) & (out['status'] == ref['status'])
+            err = max(cases.rel_err(out[k][..., same], ref[k][..., same]) for k in ('obs', 'act', 'rew'))
+            if err > 1e-9 or not same.all():
+                bad += 1
+                print(f'wrapped {cases.KIND_NAMES[kind]:7s} {"-".join(wrap.ops)} {pol} seed {seed}: err {err:.2e}, '
+                      f'{int((~same).sum())} envs differ in length/status', flush=True)
+    print(f'wrapped {cases.KIND_NAMES[kind]:7s} {"-".join(wrap0.ops)} done', flush=True)
 print(f'{bad} cases above 1e-9')
