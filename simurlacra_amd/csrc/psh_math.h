@@ -79,7 +79,7 @@ PSH_MATH double psh_tanh(double x) {
 // |x| = a_j + d with a_j the nearest table node, take T_j = tanh(a_j) from the table (`tab` may live in LDS or in
 // global memory; the lookup runs on the LDS pipe, not on the vector ALU) and tanh d from its odd series.
 //
-// Fine table, tanh(j/256), j = 0..5120, |d| <= 2^-9 (18 vector instructions, about 1.2 ulp, 2 ulp next to 0):
+// Fine table, tanh(j/256), j = 0..5120, |d| <= 2^-9 (17 fp64 + 3 32-bit vector instructions, about 1.2 ulp, 2 ulp next to 0):
 //   tanh(a_j + d) = T + (1 - T^2) td / (1 + T td),   1/(1 + u) = (1 - u)(1 + u^2 + u^4) + O(u^6),  u = T td <= 2^-9.
 // Adding 1.5 * 2^44 rounds |x| to a multiple of 1/256 and leaves that multiple in the low word of the sum.
 // The work is split into an index step and a finish step so that a caller can issue all its table loads first.
@@ -97,11 +97,13 @@ PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
     const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;   // 2/15, -1/3; d^7 is below 2^-58
     const double td = fma(p, d, d);
     const double u = T * td;
-    const double S = fma(-T, T, 1.0);
     const double r0 = 1.0 - u;
     const double e = u * u;
     const double w = fma(r0, fma(e, e, e), r0);
-    return copysign(fma(S, td * w, T), x);
+    // (1 - T^2) td w = w (td - T u): one instruction less than forming 1 - T^2; the cancellation in td - T u loses
+    // bits of a term that is itself below 2^-9 of the result
+    const double g = fma(-T, u, td);
+    return copysign(fma(w, g, T), x);
 }
 PSH_MATH double psh_tanh8(double x, const double* tab) {
     double d;
