@@ -84,13 +84,21 @@ PSH_MATH double psh_tanh(double x) {
 // Adding 1.5 * 2^44 rounds |x| to a multiple of 1/256 and leaves that multiple in the low word of the sum.
 // The work is split into an index step and a finish step so that a caller can issue all its table loads first.
 #define PSH_TANH8_N 5121
-PSH_MATH unsigned psh_tanh8_index(double x, double* d) {
-    double a = fabs(x);
-    a = (a > 20.0) ? 20.0 : a;                 // tanh(20) rounds to 1; a NaN passes through d to the result
+//
+// |x| is clamped in the integer domain (two 32-bit instructions instead of an fp64 compare and two selects): with
+// the high word limited to that of 20.0, a lies in [20, 20 + 2^-16), which is node 5120 with T = 1 and 1 - T^2 = 0,
+// so the result is exactly 1.  The clamp also turns a NaN into ~20: the caller gets |x|'s high word back (`hi_abs`)
+// and restores the NaN itself; x is a NaN iff hi_abs > PSH_HI_INF (arithmetic only produces quiet NaNs, whose high
+// word is >= 0x7ff80000).
+#define PSH_HI_INF 0x7ff00000u
+PSH_MATH unsigned psh_tanh8_index(double x, double* d, unsigned* hi_abs) {
+    const unsigned hi = (unsigned)__double2hiint(x) & 0x7fffffffu;
+    *hi_abs = hi;
+    const unsigned hc = hi < 0x40340000u ? hi : 0x40340000u;           // high word of 20.0
+    const double a = __hiloint2double((int)hc, __double2loint(x));
     const double jm = a + 26388279066624.0;    // 1.5 * 2^44
     *d = a - (jm - 26388279066624.0);
-    const unsigned j = (unsigned)__double2loint(jm);
-    return j > 5120u ? 5120u : j;              // only a NaN with payload bits can get here out of range
+    return (unsigned)__double2loint(jm);       // <= 5120 by the clamp
 }
 PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
     const double z = d * d;
@@ -107,8 +115,10 @@ PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
 }
 PSH_MATH double psh_tanh8(double x, const double* tab) {
     double d;
-    const unsigned j = psh_tanh8_index(x, &d);
-    return psh_tanh8_finish(x, d, tab[j]);
+    unsigned hi;
+    const unsigned j = psh_tanh8_index(x, &d, &hi);
+    const double r = psh_tanh8_finish(x, d, tab[j]);
+    return hi > PSH_HI_INF ? x : r;
 }
 
 // Coarse table, tanh(j/64), j = 0..1280, |d| <= 2^-7 (23 vector instructions, 2 ulp): for kernels whose LDS has no

@@ -501,19 +501,29 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 // the widest, deepest networks leave no room for it and run with the coarse one.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// y[0..N) are the pre-activations this lane holds for ONE environment; all of them feed every unit of the next
+// layer, so a NaN in any of them has to end up in the action.  The fine-table tanh loses NaNs (its clamp works on
+// the high word), so the largest |y| high word of the layer is tracked (one 32-bit max per element) and a NaN is put
+// back into y[0] once per layer.
 template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
         if (FINE) {
+            unsigned hi_max = 0;
             // all table loads first, then the arithmetic: the LDS latency is paid once per layer, not per element
             constexpr int CH = N < 8 ? N : 8;  // chunked: d and T of a whole layer would not fit the register file
 #pragma unroll
             for (int m0 = 0; m0 < N; m0 += CH) {
                 double d[CH], T[CH];
 #pragma unroll
-                for (int m = 0; m < CH; ++m) T[m] = tanh_tab[psh_tanh8_index(y[m0 + m], &d[m])];
+                for (int m = 0; m < CH; ++m) {
+                    unsigned hi;
+                    T[m] = tanh_tab[psh_tanh8_index(y[m0 + m], &d[m], &hi)];
+                    hi_max = hi > hi_max ? hi : hi_max;
+                }
 #pragma unroll
                 for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
             }
+            y[0] = hi_max > PSH_HI_INF ? __builtin_nan("") : y[0];
         } else {
 #pragma unroll
             for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
