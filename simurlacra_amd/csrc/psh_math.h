@@ -125,13 +125,14 @@ PSH_MATH double psh_tanh8(double x, const double* tab) {
 // room for the fine table.  tanh(a_j + d) = (T + td)/(1 + T td) with a series seed of the reciprocal and one
 // residual correction of the quotient.
 #define PSH_TANH_TAB_N 1281
-PSH_MATH double psh_tanh_tab(double x, const double* tab) {
-    double a = fabs(x);
-    a = (a > 20.0) ? 20.0 : a;
-    const double jd = rint(a * 64.0);
-    const int j = (int)jd;                      // NaN converts to 0
-    const double d = fma(jd, -0.015625, a);     // exact
-    const double T = tab[j];
+PSH_MATH double psh_tanh_tab(double x, const double* tab, unsigned* hi_abs) {
+    const unsigned hi = (unsigned)__double2hiint(x) & 0x7fffffffu;   // clamp and NaN handling as in psh_tanh8_index
+    *hi_abs = hi;
+    const unsigned hc = hi < 0x40340000u ? hi : 0x40340000u;
+    const double a = __hiloint2double((int)hc, __double2loint(x));
+    const double jm = a + 105553116266496.0;    // 1.5 * 2^46: rounds to a multiple of 1/64, the multiple in the low word
+    const double d = a - (jm - 105553116266496.0);
+    const double T = tab[(unsigned)__double2loint(jm)];
     const double z = d * d;
     double p = fma(z, -5.396825396825397e-02, 1.3333333333333333e-01);   // -17/315, 2/15
     p = fma(p, z, -3.3333333333333331e-01);

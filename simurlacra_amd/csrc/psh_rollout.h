@@ -502,13 +502,13 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // y[0..N) are the pre-activations this lane holds for ONE environment; all of them feed every unit of the next
-// layer, so a NaN in any of them has to end up in the action.  The fine-table tanh loses NaNs (its clamp works on
+// layer, so a NaN in any of them has to end up in the action.  The table tanh loses NaNs (its clamp works on
 // the high word), so the largest |y| high word of the layer is tracked (one 32-bit max per element) and a NaN is put
 // back into y[0] once per layer.
 template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
+        unsigned hi_max = 0;
         if (FINE) {
-            unsigned hi_max = 0;
             // all table loads first, then the arithmetic: the LDS latency is paid once per layer, not per element
             constexpr int CH = N < 8 ? N : 8;  // chunked: d and T of a whole layer would not fit the register file
 #pragma unroll
@@ -523,11 +523,15 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
 #pragma unroll
                 for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
             }
-            y[0] = hi_max > PSH_HI_INF ? __builtin_nan("") : y[0];
         } else {
 #pragma unroll
-            for (int m = 0; m < N; ++m) y[m] = psh_tanh_tab(y[m], tanh_tab);
+            for (int m = 0; m < N; ++m) {
+                unsigned hi;
+                y[m] = psh_tanh_tab(y[m], tanh_tab, &hi);
+                hi_max = hi > hi_max ? hi : hi_max;
+            }
         }
+        y[0] = hi_max > PSH_HI_INF ? __builtin_nan("") : y[0];
     } else if (nl == PSH_NL_SIGMOID) {
 #pragma unroll
         for (int m = 0; m < N; ++m) y[m] = psh_sigmoid(y[m]);

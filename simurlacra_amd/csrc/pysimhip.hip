@@ -251,7 +251,12 @@ __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* 
     case 3: psh_sincos(x[i], &s, &c); y[i] = s; break;
     case 4: psh_sincos(x[i], &s, &c); y[i] = c; break;
     case 6: y[i] = psh_tanh8(x[i], tanh_tab); break;
-    case 7: y[i] = psh_tanh_tab(x[i], tanh_tab + PSH_TANH8_N); break;
+    case 7: {
+        unsigned hi;
+        const double r = psh_tanh_tab(x[i], tanh_tab + PSH_TANH8_N, &hi);
+        y[i] = hi > PSH_HI_INF ? x[i] : r;
+        break;
+    }
     default: y[i] = psh_fmod(x[i], m[i]);
     }
 }
