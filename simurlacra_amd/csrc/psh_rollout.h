@@ -541,7 +541,10 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
     }
 }
 
-template <int KIND, int HP, bool FINE, bool WRAP, bool POP>
+// TANH: every hidden layer uses tanh, known at compile time.  With the nonlinearity chosen at run time the arms of
+// the switch meet again behind each layer and the register allocator moves all 16 activations of a tile into a common
+// place on every arm (32 v_mov_b64 per tile and layer, 3 % of the step); the usual all-tanh network does not pay that.
+template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH>
 __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[0], y, tanh_tab);
+                nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
             }
             // further hidden layers
             int off = HT * K0 * 64 + HP;
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                nl_apply_all<KS, FINE>(a.pol.hidden_nonlin[l], y, tanh_tab);
+                nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
@@ -820,7 +823,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
     if (p.n_hidden < 1 || p.n_hidden > PSH_MAX_HIDDEN) { set_err(c, "FNNPolicy needs 1..4 hidden layers"); return PSH_ERR_ARG; }
     int hmax = 0, np = 0, last = Oe;
+    bool all_tanh = true;
     for (int l = 0; l < p.n_hidden; ++l) {
+        all_tanh = all_tanh && p.hidden_nonlin[l] == PSH_NL_TANH;
         const int h = p.hidden[l];
         if (h < 1 || h > PSH_MAX_WIDTH) { set_err(c, "hidden sizes must be within 1..64"); return PSH_ERR_ARG; }
         if (p.hidden_nonlin[l] < 0 || p.hidden_nonlin[l] > PSH_NL_SIGMOID) { set_err(c, "unknown nonlinearity"); return PSH_ERR_ARG; }
@@ -853,12 +858,12 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         a.tanh_n = PSH_TANH8_N;
         const size_t lds_pop = ((size_t)(BLOCK / 64) * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
         const long lanes = (long)p.n_policies * ((p.policy_group + 15) / 16) * 16;
-#define PSH_LAUNCH_POP(HP_)                                                                                              \
-    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, true>, BLOCK, lds_pop, a, E::A, has_delay, st, lanes) \
-             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true>, BLOCK, lds_pop, a, E::A, false, st, lanes))
-        if (HP == 16) return PSH_LAUNCH_POP(16);
-        if (HP == 32) return PSH_LAUNCH_POP(32);
-        return PSH_LAUNCH_POP(64);
+#define PSH_LAUNCH_POP(HP_, TANH_)                                                                                       \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, true, TANH_>, BLOCK, lds_pop, a, E::A, has_delay, st, lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true, TANH_>, BLOCK, lds_pop, a, E::A, false, st, lanes))
+        if (HP == 16) return all_tanh ? PSH_LAUNCH_POP(16, true) : PSH_LAUNCH_POP(16, false);
+        if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, true) : PSH_LAUNCH_POP(32, false);
+        return all_tanh ? PSH_LAUNCH_POP(64, true) : PSH_LAUNCH_POP(64, false);
 #undef PSH_LAUNCH_POP
     }
     const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;
@@ -867,12 +872,12 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
     const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
     if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
-#define PSH_LAUNCH_FNN(HP_, FINE_)                                                                                       \
-    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false>, BLOCK, lds_bytes, a, E::A, has_delay, st) \
-             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false>, BLOCK, lds_bytes, a, E::A, false, st))
-    if (HP == 16) return PSH_LAUNCH_FNN(16, true);
-    if (HP == 32) return PSH_LAUNCH_FNN(32, true);
-    if (fine) return PSH_LAUNCH_FNN(64, true);
-    return PSH_LAUNCH_FNN(64, false);
+#define PSH_LAUNCH_FNN(HP_, FINE_, TANH_)                                                                                \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false, TANH_>, BLOCK, lds_bytes, a, E::A, has_delay, st) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false, TANH_>, BLOCK, lds_bytes, a, E::A, false, st))
+    if (HP == 16) return all_tanh ? PSH_LAUNCH_FNN(16, true, true) : PSH_LAUNCH_FNN(16, true, false);
+    if (HP == 32) return all_tanh ? PSH_LAUNCH_FNN(32, true, true) : PSH_LAUNCH_FNN(32, true, false);
+    if (fine) return all_tanh ? PSH_LAUNCH_FNN(64, true, true) : PSH_LAUNCH_FNN(64, true, false);
+    return all_tanh ? PSH_LAUNCH_FNN(64, false, true) : PSH_LAUNCH_FNN(64, false, false);
 #undef PSH_LAUNCH_FNN
 }
