@@ -578,6 +578,8 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
         double obs[OP], act[E::A];
 #pragma unroll
         for (int r = 0; r < OP; ++r) obs[r] = 0.;
+#pragma unroll
+        for (int r = 0; r < E::A; ++r) act[r] = 0.;  // lanes of skipped tiles get no action
         if (L.live) L.pre_policy(a, wrap, obs);
         if (!__any(L.live)) continue;
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
@@ -662,8 +664,16 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
                 p += wo[E::A * HP + r];
-                nl_apply_all<1, FINE>(a.pol.out_nonlin, &p, tanh_tab);
                 if (q == tile) act[r] = p;
+            }
+        }
+        // output nonlinearity, once per lane on its own action.  A branch the compiler must keep: without side
+        // effects in it, all nonlinearities were evaluated speculatively and selected from (as they were per tile)
+        if (a.pol.out_nonlin != PSH_NL_NONE) {
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) {
+                asm volatile("" : "+v"(act[r]));
+                nl_apply_all<1, FINE>(a.pol.out_nonlin, &act[r], tanh_tab);
             }
         }
         if (L.live) L.post_policy(a, task, wrap, act);
