@@ -545,7 +545,7 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
 // the switch meet again behind each layer and the register allocator moves all 16 activations of a tile into a common
 // place on every arm (32 v_mov_b64 per tile and layer, 3 % of the step); the usual all-tanh network does not pay that.
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH>
-__global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
+__global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512) void k_rollout_fnn(const RolloutArgs a) {
     // a population do not fit into LDS; they stay resident in L2 / Infinity Cache), LDS holds no weights
     const int w_doubles = POP ? 0 : a.lds_doubles;
     double* const stage = lds + w_doubles + wave * (OP * 64);
-    double* const tanh_tab = lds + w_doubles + 8 * (OP * 64);
+    double* const tanh_tab = lds + w_doubles + (int)(blockDim.x >> 6) * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
     const double* const task_base = opaque_lds_base(task_lds);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
@@ -862,7 +862,12 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
     a.lds_doubles = total;
-    constexpr int BLOCK = 512;
+    // 8 waves per workgroup (2 per SIMD) or 12 (3 per SIMD, which the 168 registers of the bare kernels allow).  The third
+    // wave hides more latency (+1..9 % throughput while the queue lasts), but every wave then steps 1.5 times slower,
+    // and so does the drain at the end of a launch, when the last long episodes run alone: worth it only with enough
+    // environments queued per lane.
+    const long lanes12 = (long)c->num_cus * 768;
+    const int BLOCK = (!per_env && !wrapped && (long)d->n_envs >= 8 * lanes12) ? 768 : 512;
     if (per_env) {  // population: weights stay in global memory, work is handed out per 16-lane tile
         a.tanh_tab = c->tanh_tab;
         a.tanh_n = PSH_TANH8_N;
