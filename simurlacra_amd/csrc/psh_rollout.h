@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <type_traits>
 
 #include "psh_ctx.h"
 #include "psh_env.h"
@@ -541,6 +542,20 @@ template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const d
     }
 }
 
+// Sends the whole state of this lane (a trivially copyable struct) to lane `dst`; `dst` must be a permutation of the
+// wave's lanes.  Which lane runs an environment has no influence on its results.
+template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
+    static_assert(std::is_trivially_copyable<T>::value, "moved as raw words");
+    constexpr int W = (sizeof(T) + 3) / 4;
+    int w[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) w[j] = 0;
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int j = 0; j < W; ++j) w[j] = __builtin_amdgcn_ds_permute(dst << 2, w[j]);
+    __builtin_memcpy(&v, w, sizeof(T));
+}
+
 // TANH: every hidden layer uses tanh, known at compile time.  With the nonlinearity chosen at run time the arms of
 // the switch meet again behind each layer and the register allocator moves all 16 activations of a tile into a common
 // place on every arm (32 v_mov_b64 per tile and layer, 3 % of the step); the usual all-tanh network does not pay that.
@@ -575,6 +590,25 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     for (;;) {
         if constexpr (POP) pol = L.turnover_tile(a, task, wrap, pol); else L.turnover(a, task, wrap);
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
+        if constexpr (!POP) {
+            // The drain: once the queue is empty, finished lanes leave holes, and a tile costs its MFMAs as long as one
+            // of its 16 lanes is busy.  Whenever the busy lanes would fit into fewer tiles than they occupy, the
+            // environments of the wave are moved together (at most three times per wave).
+            // (not with an ActDelayWrapper: its ring buffer belongs to the lane, not to the environment)
+            if ((!WRAP || a.delay_q == nullptr) && __any(L.exhausted)) {
+                const unsigned long long busy = __ballot(L.i >= 0);
+                const int n_busy = __popcll(busy);
+                int tiles = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) tiles += ((busy >> (16 * t)) & 0xFFFFull) != 0;
+                if ((n_busy + 15) / 16 < tiles) {
+                    const unsigned long long idle = ~busy;
+                    const int rank_busy = __builtin_amdgcn_mbcnt_hi((unsigned)(busy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)busy, 0u));
+                    const int rank_idle = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                    move_lane_state(L, L.i >= 0 ? rank_busy : n_busy + rank_idle);
+                }
+            }
+        }
         double obs[OP], act[E::A];
 #pragma unroll
         for (int r = 0; r < OP; ++r) obs[r] = 0.;
