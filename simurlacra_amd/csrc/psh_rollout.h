@@ -897,11 +897,11 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     a.wfrag = c->wfrag;
     a.lds_doubles = total;
     // 8 waves per workgroup (2 per SIMD) or 12 (3 per SIMD, which the 168 registers of the bare kernels allow).  The third
-    // wave hides more latency (+1..9 % throughput while the queue lasts), but every wave then steps 1.5 times slower,
-    // and so does the drain at the end of a launch, when the last long episodes run alone: worth it only with enough
-    // environments queued per lane.
+    // wave hides more latency (+2..9 % throughput while the queue lasts), but every wave then steps 1.5 times slower,
+    // and so does the drain at the end of a launch: taken when the queue fills the larger grid at least twice
+    // (measured at 2 and 5 envs per lane: ahead for 6 of 8 environment kinds, within 4 % for the others).
     const long lanes12 = (long)c->num_cus * 768;
-    const int BLOCK = (!per_env && !wrapped && (long)d->n_envs >= 8 * lanes12) ? 768 : 512;
+    const int BLOCK = (!per_env && !wrapped && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
     if (per_env) {  // population: weights stay in global memory, work is handed out per 16-lane tile
         a.tanh_tab = c->tanh_tab;
         a.tanh_n = PSH_TANH8_N;
