@@ -118,9 +118,11 @@ template <int KIND, bool WRAP> struct Lane {
     int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
     bool done, live;  // live: this lane still has steps to execute
     bool exhausted;   // the work queue had nothing left for this lane
+    unsigned int chunk_next, chunk_end;  // wave-uniform: the envs of this wave's current chunk not handed out yet
     bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
 
-    PSH_DEV void init() { i = -1; live = false; exhausted = false; }
+    static constexpr int QUEUE_CHUNK = 8;
+    PSH_DEV void init() { i = -1; live = false; exhausted = false; chunk_next = chunk_end = 0; }
 
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
@@ -134,10 +136,41 @@ template <int KIND, bool WRAP> struct Lane {
             if (__popcll(__ballot(want)) < BATCH && __any(live)) return;
         }
         if (i >= 0 && !live) { store(a, wrap); i = -1; }
-        if (i < 0 && !exhausted) {
-            const unsigned int nxt = atomicAdd(a.queue, 1u);
-            if (nxt < (unsigned int)a.n_envs) { i = (long)nxt; load(a, task, wrap); } else { exhausted = true; }
+        // The queue is drawn from in chunks of 8 consecutive envs per wave: row r of the inputs of such a chunk is one
+        // 64-byte line, fetched once and still in L2 when the wave's next free lane takes the neighbouring env (single
+        // envs handed out across all waves cost a line per 8-byte value: 1.8 GB of HBM reads per launch for 0.24 GB of
+        // inputs); the 8-byte results of a chunk likewise merge into whole lines.  All lanes of the wave get here
+        // together, so the chunk bounds are wave-uniform.
+        bool want = i < 0 && !exhausted, fresh = false;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (chunk_next == chunk_end) {
+                // one draw covers every lane that is waiting, in whole lines (the first fill of a wave takes 64 at once:
+                // eight draws each would queue eight times as many atomics of all waves on one address)
+                const unsigned int size = ((unsigned int)__popcll(m) + QUEUE_CHUNK - 1) / QUEUE_CHUNK * QUEUE_CHUNK;
+                unsigned int base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(a.queue, size);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned int n = (unsigned int)a.n_envs;
+                chunk_next = base < n ? base : n;
+                chunk_end = base + size < n ? base + size : n;
+                if (chunk_next == chunk_end) {  // the queue is empty
+                    if (want) exhausted = true;
+                    break;
+                }
+            }
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned int avail = chunk_end - chunk_next;
+            if (want && rank < avail) {
+                i = (long)(chunk_next + rank);
+                want = false;
+                fresh = true;
+            }
+            const unsigned int asked = (unsigned int)__popcll(m);
+            chunk_next += asked < avail ? asked : avail;
+            m = __ballot(want);
         }
+        if (fresh) load(a, task, wrap);  // once for all lanes that got an env, whatever chunks they came from
     }
 
     // Population mode of the FNN kernel: the 16 lanes of an MFMA tile must share one policy, so work is handed out per
