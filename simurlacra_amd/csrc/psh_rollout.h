@@ -529,9 +529,10 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 // overlap, also not between waves), so every vector instruction next to the MFMAs costs throughput: the activation
 // function is the table-based psh_tanh_tab and the loop keeps its constants in LDS rather than in registers.
 //
-// Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = OP/4 with OP = observation rows padded to 4:
-//   [HT*K0 frags of 64][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then [Wout: A*HP][bout: 2]
-// Dynamic LDS: [weight image][8 staging areas of OP*64][tanh table][task].  FINE selects the fine tanh table (40 KB);
+// Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = O/4 whole groups of 4 inputs, REM = O%4 inputs left over:
+//   [HT*K0 frags of 64][Wrem: REM*HP][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then
+//   [Wout: A*HP][bout: 2]
+// Dynamic LDS: [weight image][a staging area of OP*64 per wave, OP = O padded to 4][tanh table][task].  FINE selects the fine tanh table (40 KB);
 // the widest, deepest networks leave no room for it and run with the coarse one.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -595,7 +596,9 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH>
 __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
-    constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = OP / 4;
+    // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
+    // vector ALU (16 FMAs each per tile) instead of through a k-step that is half zeros (QQube's 6 inputs: 4 + 2)
+    constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = E::O / 4, REM = E::O % 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* const w_lds = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -670,16 +673,24 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
             double y[KS];
             // layer 0
             {
-                double xin[K0];
+                double xin[K0 > 0 ? K0 : 1], xr[REM > 0 ? REM : 1];
 #pragma unroll
                 for (int s = 0; s < K0; ++s) xin[s] = stage[(4 * s + q) * 64 + 16 * tile + c];
+#pragma unroll
+                for (int j = 0; j < REM; ++j) xr[j] = stage[(4 * K0 + j) * 64 + 16 * tile + c];  // of this lane's env
                 const double* wl = wimg;
-                const double* bl = wimg + HT * K0 * 64;
+                const double* wr = wimg + HT * K0 * 64;  // [REM][HP]: weights of the left-over inputs
+                const double* bl = wr + REM * HP;
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
                     v4d acc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * t + 4 * r + q;
+                        acc[r] = bl[row];
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) acc[r] = fma(wr[j * HP + row], xr[j], acc[r]);
+                    }
 #pragma unroll
                     for (int s = 0; s < K0; ++s)
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * K0 + s) * 64 + lane], xin[s], acc, 0, 0, 0);
@@ -689,7 +700,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                 nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
             }
             // further hidden layers
-            int off = HT * K0 * 64 + HP;
+            int off = HT * K0 * 64 + REM * HP + HP;
             for (int l = 1; l < n_hidden; ++l) {
                 double x[KS];
 #pragma unroll
@@ -750,31 +761,37 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
 template <int KIND>
 __global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict__ out, int total, int O, int A, int HP,
-                           int OP, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
+                           int K0, int REM, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     params += (long)blockIdx.y * num_param;  // one image per policy (blockIdx.y)
     out += (long)blockIdx.y * total;
     const int hs[4] = {h0, h1, h2, h3};
-    const int HT = HP / 16, KS = HP / 4, K0 = OP / 4;
+    const int HT = HP / 16, KS = HP / 4;
     int off = 0, poff = 0, last = O;
     double v = 0.;
     bool found = false;
     for (int l = 0; l < n_hidden && !found; ++l) {
         const int ks = (l == 0) ? K0 : KS, h = hs[l];
         const int nfrag = HT * ks * 64;
+        const int nrem = (l == 0) ? REM * HP : 0;  // layer 0: weights of the inputs beyond the last whole group of 4
         if (idx < off + nfrag) {
             const int f = (idx - off) >> 6, lane = (idx - off) & 63;
             const int t = f / ks, s = f % ks;
             const int row = 16 * t + (lane & 15), col = 4 * s + (lane >> 4);
             v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
             found = true;
-        } else if (idx < off + nfrag + HP) {
+        } else if (idx < off + nfrag + nrem) {
             const int j = idx - off - nfrag;
+            const int row = j % HP, col = 4 * K0 + j / HP;
+            v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
+            found = true;
+        } else if (idx < off + nfrag + nrem + HP) {
+            const int j = idx - off - nfrag - nrem;
             v = (j < h) ? params[poff + h * last + j] : 0.;
             found = true;
         }
-        off += nfrag + HP;
+        off += nfrag + nrem + HP;
         poff += h * last + h;
         last = h;
     }
@@ -917,14 +934,14 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         return PSH_ERR_UNSUPPORTED;
     }
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
-    const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = OP / 4;
-    const int total = HT * K0 * 64 + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
+    const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = E::O / 4, REM = E::O % 4;
+    const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
     {
         const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total * (per_env ? p.n_policies : 1));
         if (rc != PSH_OK) return rc;
     }
     hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256, per_env ? p.n_policies : 1), dim3(256), 0, st, p.params,
-                       c->wfrag, total, Oe, (int)E::A, HP, OP, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
+                       c->wfrag, total, Oe, (int)E::A, HP, K0, REM, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
                        p.num_param);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = c->wfrag;
