@@ -951,7 +951,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // and so does the drain at the end of a launch: taken when the queue fills the larger grid at least twice
     // (measured at 2 and 5 envs per lane: ahead for 6 of 8 environment kinds, within 4 % for the others).
     const long lanes12 = (long)c->num_cus * 768;
-    const int BLOCK = (!per_env && !wrapped && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
+    // (and only if the four extra staging areas do not push the fine tanh table out of LDS)
+    const bool fits12 = ((size_t)total + 12 * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
+    const int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
     if (per_env) {  // population: weights stay in global memory, work is handed out per 16-lane tile
         a.tanh_tab = c->tanh_tab;
         a.tanh_n = PSH_TANH8_N;

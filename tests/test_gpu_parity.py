@@ -405,6 +405,27 @@ def test_full_size_launch_is_order_invariant_and_matches_the_oracle_on_a_sample(
     assert cases.rel_err(out['ret'].cpu().numpy()[sample], ref['ret']) <= 1e-6
 
 
+def test_large_launches_of_deeper_nets(eng, orc):
+    """ Launch sizes at which the bare FNN kernel runs 12 waves per workgroup, with weight images of growing size (the
+    staging areas of the extra waves must not cost the network its tanh table or its place in LDS): returns of a
+    sample against the oracle. """
+    import torch
+    kind, n, T = abi.ENV_QQ, 420000, 12
+    rng = np.random.default_rng(3)
+    dp = cases.domain_params(kind, n, rng)
+    init = cases.init_states(kind, dp, rng)
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    sample = rng.choice(n, 500, replace=False)
+    for hidden in ((64, 64), (64, 64, 64), (64, 64, 64, 64)):
+        ps, params = cases.fnn_policy(kind, np.random.default_rng(len(hidden)), hidden=hidden, scale=0.2)
+        out = eng.rollout(kind, cases.DT[kind], T, task_c, ps, params, torch.as_tensor(init, device=eng.device),
+                          torch.as_tensor(dp, device=eng.device))
+        ref = orc.rollout(kind, cases.DT[kind], T, task_c, ps, params, init[:, sample], dp[:, sample])
+        np.testing.assert_array_equal(out['length'].cpu().numpy()[sample], ref['length'])
+        assert cases.rel_err(out['ret'].cpu().numpy()[sample], ref['ret']) <= TOL
+
+
 def test_ragged_and_empty_batches(eng, orc):
     """ N not a multiple of the wave/block size, N = 1 and N = 0 """
     kind = abi.ENV_QQ
