@@ -599,6 +599,12 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
     // vector ALU (16 FMAs each per tile) instead of through a k-step that is half zeros (QQube's 6 inputs: 4 + 2)
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = E::O / 4, REM = E::O % 4;
+    // Wave priorities by phase of the step.  The MFMA blocks of the hidden layers are long runs of independent
+    // instructions, the environment step and the activations are dependent chains with table and LDS latencies in
+    // them: when the chains of one wave go first and the MFMAs of another fill what they leave open, the pipe idles
+    // less than under the default oldest-first issue (1.2-1.6 % of the launch; any other assignment of the three
+    // levels gains less, a fixed priority per wave nothing).
+    constexpr int PRIO_MFMA = 0, PRIO_ACT = 2, PRIO_ENV = 3;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* const w_lds = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -660,6 +666,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         const unsigned long long live_mask = __ballot(L.live);
+        __builtin_amdgcn_s_setprio(PRIO_ACT);
         for (int tile = 0; tile < 4; ++tile) {
             // nobody in this tile needs an action: skip it (the drain at the end of a launch, when few long episodes
             // are left, then costs a quarter per step; partially filled population tiles)
@@ -707,6 +714,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                 for (int m = 0; m < KS; ++m) x[m] = y[m];
                 const double* wl = wimg + off;
                 const double* bl = wl + HT * KS * 64;
+                __builtin_amdgcn_s_setprio(PRIO_MFMA);
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
                     v4d acc;
@@ -729,6 +737,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
+                __builtin_amdgcn_s_setprio(PRIO_ACT);
                 nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
@@ -745,6 +754,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                 if (q == tile) act[r] = p;
             }
         }
+        __builtin_amdgcn_s_setprio(PRIO_ENV);
         // output nonlinearity, once per lane on its own action.  A branch the compiler must keep: without side
         // effects in it, all nonlinearities were evaluated speculatively and selected from (as they were per tile)
         if (a.pol.out_nonlin != PSH_NL_NONE) {
