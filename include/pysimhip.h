@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 106
+#define PSH_VERSION 107
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -189,6 +189,8 @@ typedef struct psh_policy {
 #define PSH_ST_FAILED 2   /* state left the (inclusive) state-space box: task.has_failed        */
 #define PSH_ST_TIMEOUT 4  /* curr_step reached max_steps                                        */
 #define PSH_ST_BERNOULLI 8 /* rollout ended by the stochastic reset (bernoulli_reset)           */
+#define PSH_ST_BAD_INDEX 16 /* dp_index[i] or policy_index[i] points outside its table: the env is
+                              not run (length 0, return 0); nothing outside the tables is read  */
 
 /* Environment wrappers fused into the rollout (Pyrado/pyrado/environment_wrappers/): what EnvWrapperAct.step
  * and EnvWrapperObs.reset/step (base.py:145-231) do around the simulation each step.  `ops` lists the wrappers
@@ -270,7 +272,9 @@ typedef struct psh_rollout_desc {
     int32_t ld_init;
     /* domain parameters: [P, M] table, ld = ld_dp.  dp_index == NULL: M == N and env i reads column i;
      * else env i reads column dp_index[i] (buffer / sweep mode: DomainRandWrapperBuffer,
-     * Pyrado/pyrado/environment_wrappers/domain_randomization.py:179-199). */
+     * Pyrado/pyrado/environment_wrappers/domain_randomization.py:179-199).  The kernels follow no entry outside
+     * [0, ld_dp): such an env (likewise one whose policy_index entry is outside [0, n_policies)) is not run and
+     * reports PSH_ST_BAD_INDEX; psh_sample_init, which has no status word, gives it a NaN init state. */
     const double* domain_param; /* [dev] */
     const int32_t* dp_index;    /* [dev] or NULL */
     int32_t ld_dp;

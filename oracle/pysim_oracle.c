@@ -689,6 +689,12 @@ static void rollout_one(const psh_rollout_desc* d, int i, const int32_t dims[5])
     e.simplified = (d->flags & PSH_F_SIMPLIFIED_DYN) != 0;
     double dp[PSH_MAX_DP], init[PSH_MAX_STATE];
     int col = d->dp_index ? d->dp_index[i] : i;
+    if (col < 0 || col >= d->ld_dp ||
+        (d->policy.policy_index && (d->policy.policy_index[i] < 0 || d->policy.policy_index[i] >= d->policy.n_policies))) {
+        /* an index outside its table (the library's own rule, no counterpart in the reference): the env is not run */
+        d->ret[i] = 0.; d->length[i] = 0; d->status[i] = PSH_ST_BAD_INDEX;
+        return;
+    }
     for (int r = 0; r < P; ++r) dp[r] = d->domain_param[(size_t)r * d->ld_dp + col];
     for (int r = 0; r < d->init_dim; ++r) init[r] = d->init_state[(size_t)r * d->ld_init + i];
     env_reset(&e, &d->task, dp, init, d->init_dim);
@@ -807,12 +813,15 @@ int orc_num_threads(void) {
 }
 
 /* ---- reset / step with caller-owned environment memory ------------------------------------------ */
-static void load_env(orc_env* e, const psh_step_desc* d, int i, const int32_t dims[5]) {
+static int load_env(orc_env* e, const psh_step_desc* d, int i, const int32_t dims[5]) {
     memset(e, 0, sizeof *e);
     e->kind = d->env_kind; e->S = dims[0]; e->O = dims[1]; e->A = dims[2]; e->P = dims[3];
     e->simplified = (d->flags & PSH_F_SIMPLIFIED_DYN) != 0;
     int col = d->dp_index ? d->dp_index[i] : i;
+    const int bad = col < 0 || col >= d->ld_dp;  /* outside the table: column 0 is read, the status word says so */
+    if (bad) col = 0;
     for (int r = 0; r < e->P; ++r) e->dp[r] = d->domain_param[(size_t)r * d->ld_dp + col];
+    return bad ? PSH_ST_BAD_INDEX : 0;
 }
 
 int orc_reset(const psh_step_desc* d) {
@@ -821,7 +830,7 @@ int orc_reset(const psh_step_desc* d) {
     const int N = d->n_envs;
     for (int i = 0; i < N; ++i) {
         orc_env e;
-        load_env(&e, d, i, dims);
+        const int bad = load_env(&e, d, i, dims);
         double dp[PSH_MAX_DP], init[PSH_MAX_STATE], obs[PSH_MAX_OBS];
         for (int r = 0; r < e.P; ++r) dp[r] = e.dp[r];
         for (int r = 0; r < d->init_dim; ++r) init[r] = d->init_state[(size_t)r * N + i];
@@ -833,7 +842,7 @@ int orc_reset(const psh_step_desc* d) {
         observe(&e, obs);
         int nan = 0;
         for (int r = 0; r < e.O; ++r) { d->obs[(size_t)r * N + i] = obs[r]; if (isnan(obs[r])) nan = 1; }
-        if (d->status) d->status[i] = nan ? PSH_ST_NAN : 0;
+        if (d->status) d->status[i] = (nan ? PSH_ST_NAN : 0) | bad;
     }
     return 0;
 }
@@ -844,7 +853,7 @@ int orc_step(const psh_step_desc* d) {
     const int N = d->n_envs;
     for (int i = 0; i < N; ++i) {
         orc_env e;
-        load_env(&e, d, i, dims);
+        const int bad = load_env(&e, d, i, dims);
         calc_constants_and_spaces(&e);
         task_reset(&e, &d->task);
         for (int r = 0; r < e.S; ++r) e.s[r] = d->state[(size_t)r * N + i];
@@ -852,7 +861,7 @@ int orc_step(const psh_step_desc* d) {
         e.curr_step = d->curr_step[i];
         e.yielded = d->flags_io[i] & 1;
         double act[PSH_MAX_ACT], obs[PSH_MAX_OBS];
-        int st = 0, done = 0;
+        int st = bad, done = 0;
         for (int r = 0; r < e.A; ++r) { act[r] = d->act[(size_t)r * N + i]; if (isnan(act[r])) st |= PSH_ST_NAN; }
         double rew = env_step(&e, &d->task, act, d->dt, d->max_steps, (d->flags & PSH_F_MAX_STEPS_INF) != 0, &done, &st);
         for (int r = 0; r < e.A; ++r) d->act[(size_t)r * N + i] = act[r];
@@ -962,6 +971,8 @@ int orc_sample_init(const psh_init_desc* d) {
     const int I = dims[4];
     for (int i = 0; i < d->n_envs; ++i) {
         int col = d->dp_index ? d->dp_index[i] : i;
+        const int bad = d->dp_index && (col < 0 || col >= d->ld_dp);  /* outside the table: a NaN init state */
+        if (bad) col = 0;
         double lo[4], hi[4], u[5];
         uint64_t env = d->env_offset + (uint64_t)i;
         for (int r = 0; r < 5; ++r) { double ub; draw2(d->seed, env, (uint32_t)r, 1u, &u[r], &ub); }
@@ -1014,7 +1025,7 @@ int orc_sample_init(const psh_init_desc* d) {
             double rad = v[0], phi = v[1];
             v[0] = rad * cos(phi); v[1] = rad * sin(phi);
         }
-        for (int r = 0; r < I; ++r) d->out[(size_t)r * d->ld_out + i] = v[r];
+        for (int r = 0; r < I; ++r) d->out[(size_t)r * d->ld_out + i] = bad ? NAN : v[r];
     }
     return 0;
 }

@@ -25,6 +25,15 @@ struct DpCol {
     PSH_DEV double operator[](int r) const { return base[r * ld + col]; }
 };
 
+// Column of env i in a domain-parameter table with `ld` columns.  An entry of the caller's dp_index array that points
+// outside the table is not followed: column 0 is read instead and *bad is set (such an env is not run).  Without
+// dp_index the column is i, which the host side has checked against the table wherever the table is read.
+PSH_DEV long dp_column(const int* dp_index, long ld, long i, bool* bad) {
+    const long col = dp_index ? (long)dp_index[i] : i;
+    *bad = dp_index != nullptr && (unsigned long)col >= (unsigned long)ld;
+    return *bad ? 0 : col;
+}
+
 template <int KIND> struct Env;
 
 // ------------------------------------------------------------------------------------------------ QQube

@@ -198,7 +198,9 @@ template <int KIND, bool WRAP> struct Lane {
     }
 
     PSH_DEV void load(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
-        const long col = a.dp_index ? (long)a.dp_index[i] : i;
+        bool bad_index;
+        const long col = dp_column(a.dp_index, a.ld_dp, i, &bad_index);
+        if (a.pol.policy_index) bad_index = bad_index || (unsigned)a.pol.policy_index[i] >= (unsigned)a.pol.n_policies;
         const DpCol p{a.domain_param, a.ld_dp, col};
         e.setup(p);
         c_max = task_c_max<KIND>(e, task);
@@ -210,8 +212,9 @@ template <int KIND, bool WRAP> struct Lane {
         } else {
             e.reset(init, a.init_dim, false);
         }
-        ret = 0.; curr_step = 0; yielded = 0; st = 0; k = 0; done = false;
-        live = a.max_steps > 0;
+        ret = 0.; curr_step = 0; yielded = 0; k = 0; done = false;
+        st = bad_index ? PSH_ST_BAD_INDEX : 0;  // not run: stored with length 0 at the next turnover
+        live = a.max_steps > 0 && !bad_index;
         if constexpr (WRAP) {
             bool has_delay = false, new_array = false;
             for (int j = 0; j < wrap.n_ops; ++j) {

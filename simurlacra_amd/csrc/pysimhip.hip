@@ -36,7 +36,8 @@ extern template int launch_rollout<PSH_ENV_QQ_ST>(psh_ctx*, const psh_rollout_de
 __global__ __launch_bounds__(256) void k_qbb_plate(const RolloutArgs a, double* plate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_envs) return;
-    const long col = a.dp_index ? (long)a.dp_index[i] : i;
+    bool bad_index;  // flagged by the rollout kernel
+    const long col = dp_column(a.dp_index, a.ld_dp, i, &bad_index);
     const DpCol p{a.domain_param, a.ld_dp, col};
     const double th_x = (a.init_dim == 8) ? a.init_state[0 * a.ld_init + i] : 0.;
     const double th_y = (a.init_dim == 8) ? a.init_state[1 * a.ld_init + i] : 0.;
@@ -60,7 +61,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_reset(const StepArg
     if (i >= a.n_envs) return;
     const long N = a.n_envs;
     E e;
-    e.setup(DpCol{a.domain_param, a.ld_dp, a.dp_index ? (long)a.dp_index[i] : i});
+    bool bad_index;
+    e.setup(DpCol{a.domain_param, a.ld_dp, dp_column(a.dp_index, a.ld_dp, i, &bad_index)});
     double init[E::S];
     for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * N + i] : 0.;
     e.reset(init, a.init_dim, (a.flags & PSH_F_SIMPLIFIED_DYN) != 0);
@@ -77,7 +79,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_reset(const StepArg
     bool nan = false;
 #pragma unroll
     for (int r = 0; r < E::O; ++r) { a.obs[r * N + i] = obs[r]; nan = nan || (obs[r] != obs[r]); }
-    if (a.status) a.status[i] = nan ? PSH_ST_NAN : 0;
+    if (a.status) a.status[i] = (nan ? PSH_ST_NAN : 0) | (bad_index ? PSH_ST_BAD_INDEX : 0);
 }
 
 template <int KIND> __global__ __launch_bounds__(256) void k_step(const StepArgs a) {
@@ -86,7 +88,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_step(const StepArgs
     if (i >= a.n_envs) return;
     const long N = a.n_envs;
     E e;
-    e.setup(DpCol{a.domain_param, a.ld_dp, a.dp_index ? (long)a.dp_index[i] : i});
+    bool bad_index;
+    e.setup(DpCol{a.domain_param, a.ld_dp, dp_column(a.dp_index, a.ld_dp, i, &bad_index)});
     const double c_max = task_c_max<KIND>(e, a.task);
 #pragma unroll
     for (int r = 0; r < E::S; ++r) e.s[r] = a.state[r * N + i];
@@ -95,7 +98,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_step(const StepArgs
         e.plate[1] = a.state[9 * N + i];
     }
     e.refresh();
-    int curr_step = a.curr_step[i], yielded = a.flags_io[i] & 1, st = 0;
+    int curr_step = a.curr_step[i], yielded = a.flags_io[i] & 1, st = bad_index ? PSH_ST_BAD_INDEX : 0;
     double act[E::A];
 #pragma unroll
     for (int r = 0; r < E::A; ++r) { act[r] = a.act[r * N + i]; if (act[r] != act[r]) st |= PSH_ST_NAN; }
@@ -163,7 +166,8 @@ struct InitArgs {
 __global__ __launch_bounds__(256) void k_sample_init(const InitArgs a) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_envs) return;
-    const long col = a.dp_index ? (long)a.dp_index[i] : i;
+    bool bad_index;  // no status word here: such an env gets a NaN init state, which its rollout reports
+    const long col = dp_column(a.dp_index, a.ld_dp, i, &bad_index);
     double lo[4], hi[4], u[5], ub;
     const uint64_t env = a.env_offset + (uint64_t)i;
     for (int r = 0; r < 5; ++r) psh_draw2(a.seed, env, (uint32_t)r, 1u, u[r], ub);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void k_sample_init(const InitArgs a) {
         sincos(phi, &sn, &cs);
         v[0] = rad * cs; v[1] = rad * sn;
     }
-    for (int r = 0; r < I; ++r) a.out[(long)r * a.ld_out + i] = v[r];
+    for (int r = 0; r < I; ++r) a.out[(long)r * a.ld_out + i] = bad_index ? __builtin_nan("") : v[r];
 }
 
 __global__ __launch_bounds__(256) void k_qbb_ik(int n, const double* th, const double* r_arm, const double* l_plate, double* ang) {

@@ -414,6 +414,10 @@ class RolloutBatch(Sequence):
     def check(self):
         """ Raise as rollout() does when an observation, action or state became NaN in any lane. """
         st = self._h()['status'][self._offset:self._offset + self._count]
+        bad = np.flatnonzero(st & abi.ST_BAD_INDEX)
+        if bad.size:
+            raise ValueErr(msg=f'Rollout {int(bad[0])} of the batch names a domain-parameter column or a policy outside '
+                               f'its table ({bad.size} in total)!')
         bad = np.flatnonzero(st & abi.ST_NAN)
         if bad.size:
             raise ValueErr(msg=f'At least one value is NaN! (rollout {int(bad[0])} of the batch, {bad.size} in total)')

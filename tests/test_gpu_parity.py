@@ -337,6 +337,49 @@ def test_buffer_mode_and_population_mode(eng, orc):
 
 
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
+def test_indices_outside_their_tables_are_not_followed(eng, orc, policy):
+    """ dp_index / policy_index entries that point outside the domain-parameter table or the policy rows: those envs
+    are not run and say so in their status word, all others are untouched (no counterpart in the reference, whose
+    Python lists raise IndexError; a kernel must not read there). """
+    kind, n = abi.ENV_QQ, 300
+    kw = dict(hidden=(16, 16)) if policy == 'fnn' else {}
+    case = cases.make_case(kind, n, seed=6, policy=policy, scale=0.3, **kw)
+    table = case['dp'][:, :16].copy()
+    rng = np.random.default_rng(3)
+    dp_index = rng.integers(0, 16, n).astype(np.int32)
+    good = dict(dp_index=dp_index.copy())
+    bad_envs = [0, 17, 63, 64, 299]
+    dp_index[bad_envs] = [16, -1, 2**30, -2**31, 1000]
+    kw = dict(dp_index=dp_index)
+    params = case['params']
+    if policy == 'linear':
+        params = 0.3*rng.standard_normal((4, case['ps'].num_param))
+        pol_index = rng.integers(0, 4, n).astype(np.int32)
+        good['policy_index'] = pol_index.copy()
+        pol_index[[5, 128]] = [4, -7]
+        bad_envs += [5, 128]
+        kw['policy_index'] = pol_index
+    ref_good = orc.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], params, case['init'], table, **good)
+    ref = orc.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], params, case['init'], table, **kw)
+    out = eng.rollout(kind, case['dt'], 40, case['task_c'], case['ps'], params, case['init'], table, **kw)
+    st, ln, ret = (out[k].cpu().numpy() for k in ('status', 'length', 'ret'))
+    ok = np.setdiff1d(np.arange(n), bad_envs)
+    assert np.all(st[bad_envs] == abi.ST_BAD_INDEX) and np.all(ln[bad_envs] == 0) and np.all(ret[bad_envs] == 0.)
+    np.testing.assert_array_equal(st, ref['status'])
+    np.testing.assert_array_equal(ln, ref['length'])
+    np.testing.assert_array_equal(ln[ok], ref_good['length'][ok])
+    assert cases.rel_err(ret, ref['ret']) <= TOL
+    # reset / step and init sampling
+    mem = eng.reset(kind, case['dt'], 40, case['task_c'], case['init'], table, dp_index=dp_index)
+    st0 = mem['status'].cpu().numpy()
+    assert np.all(st0[bad_envs[:5]] == abi.ST_BAD_INDEX) and not st0[ok].any()
+    # BallOnBeam's init space depends on the beam length, so its sampler reads the table
+    bob_table = cases.make_case(abi.ENV_BOB, 16, seed=2)['dp']
+    init = eng.sample_init(abi.ENV_BOB, n, bob_table, seed=1, dp_index=dp_index).cpu().numpy()
+    assert np.isnan(init[:, bad_envs[:5]]).all() and np.isfinite(init[:, ok]).all()
+
+
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
 @pytest.mark.parametrize('R', [1, 8, 16, 20])
 def test_population_mode(eng, orc, policy, R):
     """ ParameterExplorationSampler's layout: env j*R + r runs parameter set j.  For FNN policies the 16 environments

@@ -430,6 +430,20 @@ def test_c_oracle_reproduces_golden_vectors(path):
 
 
 # ------------------------------------------------------------------------------- the product's device RNG
+def test_indices_outside_their_tables_are_not_followed():
+    """ The library's rule for dp_index / policy_index entries outside their tables, restated in the C oracle. """
+    kind, n = abi.ENV_BOB, 40
+    case = cases.make_case(kind, n, seed=6, policy='linear')
+    table = case['dp'][:, :8].copy()
+    dp_index = (np.arange(n) % 8).astype(np.int32)
+    ref = orc.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], case['params'], case['init'], table, dp_index=dp_index.copy())
+    dp_index[[3, 39]] = [8, -1]
+    out = orc.rollout(kind, case['dt'], 20, case['task_c'], case['ps'], case['params'], case['init'], table, dp_index=dp_index)
+    assert list(out['status'][[3, 39]]) == [abi.ST_BAD_INDEX]*2 and list(out['length'][[3, 39]]) == [0, 0]
+    ok = np.setdiff1d(np.arange(n), [3, 39])
+    np.testing.assert_array_equal(out['ret'][ok], ref['ret'][ok])
+
+
 def test_philox_known_answers():
     """ Philox4x32-10 vectors of the Random123 distribution (kat_vectors) """
     assert orc.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
