@@ -173,23 +173,24 @@ template <int KIND, bool WRAP> struct Lane {
         if (fresh) load(a, task, wrap);  // once for all lanes that got an env, whatever chunks they came from
     }
 
-    // Population mode of the FNN kernel: the 16 lanes of an MFMA tile must share one policy, so work is handed out per
-    // tile.  Task q = (policy q / chunks, rollouts 16 (q % chunks) ... of that policy); a tile takes the next task
-    // when none of its lanes has an env.  Returns the policy of this lane's tile.
-    PSH_DEV int turnover_tile(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol) {
+    // Population mode of the FNN kernel: a wave runs one policy at a time, whose weight image it keeps in LDS.
+    // Task q = (policy q / groups, rollouts 64 (q % groups) ... of that policy); the wave takes the next task when none
+    // of its lanes has an env.  Returns the policy of the wave; *fresh: a new task was taken (the caller loads its
+    // weight image).
+    PSH_DEV int turnover_wave(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol, bool* fresh) {
+        *fresh = false;
         if (i >= 0 && !live) { store(a, wrap); i = -1; }
-        const int lane = threadIdx.x & 63;
-        const unsigned long long busy = __ballot(i >= 0);
-        const bool tile_free = ((busy >> (lane & 48)) & 0xFFFFull) == 0;
-        if (tile_free && !exhausted) {
-            const int R = a.pol.policy_group, chunks = (R + 15) / 16;
+        if (!__any(i >= 0) && !exhausted) {  // `exhausted` is set for all lanes together
+            const int lane = threadIdx.x & 63;
+            const int R = a.pol.policy_group, groups = (R + 63) / 64;
             unsigned int q = 0;
-            if ((lane & 15) == 0) q = atomicAdd(a.queue, 1u);
-            q = __shfl(q, lane & 48);
-            if (q < (unsigned int)(a.pol.n_policies * chunks)) {
-                pol = (int)(q / chunks);
-                const int r = 16 * (int)(q % chunks) + (lane & 15);
+            if (lane == 0) q = atomicAdd(a.queue, 1u);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q < (unsigned int)(a.pol.n_policies * groups)) {
+                pol = (int)(q / groups);
+                const int r = 64 * (int)(q % groups) + lane;
                 if (r < R) { i = (long)pol * R + r; load(a, task, wrap); }
+                *fresh = true;
             } else {
                 exhausted = true;
             }
@@ -609,20 +610,24 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     // levels gains less, a fixed priority per wave nothing).
     constexpr int PRIO_MFMA = 0, PRIO_ACT = 2, PRIO_ENV = 3;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* const w_lds = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    // POP (population mode): every tile reads the weight image of its own policy from global memory (the images of
-    // a population do not fit into LDS; they stay resident in L2 / Infinity Cache), LDS holds no weights
-    const int w_doubles = POP ? 0 : a.lds_doubles;
+    // POP (population mode): every wave has a weight image of its own in LDS, that of the policy whose rollouts it
+    // runs (streamed from global memory per MFMA fragment the weights cost several microseconds of latency per layer:
+    // 100 us per step against 4)
+    const int n_waves = (int)(blockDim.x >> 6);
+    const int w_doubles = POP ? n_waves * a.lds_doubles : a.lds_doubles;
+    double* const w_lds = lds + (POP ? wave * a.lds_doubles : 0);
     double* const stage = lds + w_doubles + wave * (OP * 64);
-    double* const tanh_tab = lds + w_doubles + (int)(blockDim.x >> 6) * (OP * 64);
+    double* const tanh_tab = lds + w_doubles + n_waves * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
     const double* const task_base = opaque_lds_base(task_lds);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
     const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
 
-    for (int j = threadIdx.x; j < w_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    if constexpr (!POP) {
+        for (int j = threadIdx.x; j < w_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
+    }
     for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
     stage_task(a, task_lds);
     __syncthreads();
@@ -631,9 +636,22 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     L.init();
 
     const int n_hidden = a.pol.n_hidden;
-    int pol = 0;  // POP: policy of this lane's tile
+    int pol = 0;  // POP: policy of this wave
     for (;;) {
-        if constexpr (POP) pol = L.turnover_tile(a, task, wrap, pol); else L.turnover(a, task, wrap);
+        if constexpr (POP) {
+            bool fresh;
+            pol = L.turnover_wave(a, task, wrap, pol, &fresh);
+            if (fresh) {  // wave-uniform.  Only this wave reads or writes its image, in program order
+                const double* src = a.wfrag + (long)pol * a.lds_doubles;
+                for (int j = lane; j < a.lds_doubles; j += 64) w_lds[j] = src[j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (!__any(L.i >= 0)) continue;  // a task without rollouts
+            }
+        } else {
+            L.turnover(a, task, wrap);
+        }
         if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
         if constexpr (!POP) {
             // The drain: once the queue is empty, finished lanes leave holes, and a tile costs its MFMAs as long as one
@@ -672,14 +690,9 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
         __builtin_amdgcn_s_setprio(PRIO_ACT);
         for (int tile = 0; tile < 4; ++tile) {
             // nobody in this tile needs an action: skip it (the drain at the end of a launch, when few long episodes
-            // are left, then costs a quarter per step; partially filled population tiles)
+            // are left, then costs a quarter per step; population tasks with fewer than 64 rollouts)
             if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;
-            const double* wimg;  // weight image of this tile's policy
-            if constexpr (POP) {
-                wimg = a.wfrag + (long)__builtin_amdgcn_readlane(pol, 16 * tile) * a.lds_doubles;
-            } else {
-                wimg = w_lds;
-            }
+            const double* const wimg = w_lds;  // weight image of this wave's policy
             double y[KS];
             // layer 0
             {
@@ -723,20 +736,9 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                     v4d acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = bl[16 * t + 4 * r + q];
-                    if constexpr (POP) {
-                        // weights come from global memory here: all fragments of this output row are requested
-                        // before the first MFMA, so their latency is paid once per row instead of once per fragment
-                        double af[KS];
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) af[s] = wl[(t * KS + s) * 64 + lane];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], x[s], acc, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < KS; ++s)
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
-                    }
+                    for (int s = 0; s < KS; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
@@ -967,17 +969,35 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // (and only if the four extra staging areas do not push the fine tanh table out of LDS)
     const bool fits12 = ((size_t)total + 12 * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
     const int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
-    if (per_env) {  // population: weights stay in global memory, work is handed out per 16-lane tile
-        a.tanh_tab = c->tanh_tab;
-        a.tanh_n = PSH_TANH8_N;
-        const size_t lds_pop = ((size_t)(BLOCK / 64) * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
-        const long lanes = (long)p.n_policies * ((p.policy_group + 15) / 16) * 16;
-#define PSH_LAUNCH_POP(HP_, TANH_)                                                                                       \
-    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, true, TANH_>, BLOCK, lds_pop, a, E::A, has_delay, st, lanes) \
-             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true, TANH_>, BLOCK, lds_pop, a, E::A, false, st, lanes))
-        if (HP == 16) return all_tanh ? PSH_LAUNCH_POP(16, true) : PSH_LAUNCH_POP(16, false);
-        if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, true) : PSH_LAUNCH_POP(32, false);
-        return all_tanh ? PSH_LAUNCH_POP(64, true) : PSH_LAUNCH_POP(64, false);
+    if (per_env) {
+        // population: one policy per wave, its weight image in LDS next to the wave's staging area; as many waves per
+        // workgroup as fit (the coarse tanh table if that makes room for one more)
+        const size_t per_wave = ((size_t)total + OP * 64) * sizeof(double);
+        const size_t fixed_fine = ((size_t)TASK_DOUBLES + TANH8_PAD) * sizeof(double);
+        const size_t fixed_coarse = ((size_t)TASK_DOUBLES + TANH_TAB_PAD) * sizeof(double);
+        const long groups = (p.policy_group + 63) / 64, tasks = (long)p.n_policies * groups;
+        auto waves_for = [&](size_t fixed) {
+            long w = c->lds_per_block > fixed ? (long)((c->lds_per_block - fixed) / per_wave) : 0;
+            return w > 8 ? 8 : w;
+        };
+        const long w_fine = waves_for(fixed_fine), w_coarse = waves_for(fixed_coarse);
+        const bool fine = w_fine >= w_coarse;
+        long W = fine ? w_fine : w_coarse;
+        if (W < 1) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
+        // no more waves per workgroup than keep every CU busy
+        while (W > 1 && tasks < (long)c->num_cus * W) W -= 1;
+        const int BLOCK_POP = 64 * (int)W;
+        a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
+        a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
+        const size_t lds_pop = (size_t)W * per_wave + (fine ? fixed_fine : fixed_coarse);
+        const long lanes = tasks * 64;
+#define PSH_LAUNCH_POP(HP_, FINE_, TANH_)                                                                                \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
+        if (HP == 16) return all_tanh ? PSH_LAUNCH_POP(16, true, true) : PSH_LAUNCH_POP(16, true, false);
+        if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, true, true) : PSH_LAUNCH_POP(32, true, false);
+        if (fine) return all_tanh ? PSH_LAUNCH_POP(64, true, true) : PSH_LAUNCH_POP(64, true, false);
+        return all_tanh ? PSH_LAUNCH_POP(64, false, true) : PSH_LAUNCH_POP(64, false, false);
 #undef PSH_LAUNCH_POP
     }
     const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;

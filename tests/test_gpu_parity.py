@@ -380,10 +380,10 @@ def test_indices_outside_their_tables_are_not_followed(eng, orc, policy):
 
 
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
-@pytest.mark.parametrize('R', [1, 8, 16, 20])
+@pytest.mark.parametrize('R', [1, 8, 16, 20, 70, 130])
 def test_population_mode(eng, orc, policy, R):
-    """ ParameterExplorationSampler's layout: env j*R + r runs parameter set j.  For FNN policies the 16 environments
-    of an MFMA tile share a policy, so the kernel hands out work per tile: R below, at and above the tile size. """
+    """ ParameterExplorationSampler's layout: env j*R + r runs parameter set j.  For FNN policies a wave runs one policy
+    at a time (its weights in LDS), up to 64 of its rollouts: R below, at and above an MFMA tile and above a wave. """
     kind, pop = abi.ENV_QCP_ST, 37
     kw = dict(hidden=(64, 32)) if policy == 'fnn' else {}
     case = cases.make_case(kind, pop*R, seed=13, policy=policy, **kw)
@@ -407,7 +407,7 @@ def test_population_mode(eng, orc, policy, R):
 
 
 def test_large_fnn_population(eng, orc):
-    """ more tile tasks than resident tiles: tiles take over new (policy, chunk) tasks """
+    """ more tasks than resident waves: waves take over new (policy, group of rollouts) tasks and reload their weights """
     kind, pop, R = abi.ENV_OMO, 3000, 4
     case = cases.make_case(kind, pop*R, seed=3, policy='fnn', hidden=(16,))
     params = 0.5*np.random.default_rng(5).standard_normal((pop, case['ps'].num_param))
