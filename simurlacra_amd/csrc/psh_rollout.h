@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 // Packed weight image (doubles), HT = HP/16, KS = HP/4, K0 = O/4 whole groups of 4 inputs, REM = O%4 inputs left over:
 //   [HT*K0 frags of 64][Wrem: REM*HP][b0: HP]  then per further hidden layer [HT*KS frags of 64][b: HP]  then
 //   [Wout: A*HP][bout: 2]
-// Dynamic LDS: [weight image][a staging area of OP*64 per wave, OP = O padded to 4][tanh table][task].  FINE selects the fine tanh table (40 KB);
+// Dynamic LDS: [weight image (POP: one per wave)][a staging area of OP*64 per wave, OP = O padded to 4][tanh table][task].  FINE selects the fine tanh table (40 KB);
 // the widest, deepest networks leave no room for it and run with the coarse one.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
