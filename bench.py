@@ -82,11 +82,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # under torch.distributed.run the collectives run even with a single rank, so one GPU exercises the RCCL path
+    if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # RCCL writes a version banner to stdout when its communicator is created: send it to stderr, stdout carries
+        # the one JSON line only
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     else:
         dist = None
     torch.cuda.set_device(local_rank)
