@@ -35,6 +35,7 @@ struct RolloutArgs {
     const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
     const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
     int tanh_n;              // its length (fine or coarse table)
+    int pop_tiles;           // FNN population mode: MFMA tiles (16 lanes each) per policy task: 1, 2 or 4
 };
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
@@ -173,28 +174,34 @@ template <int KIND, bool WRAP> struct Lane {
         if (fresh) load(a, task, wrap);  // once for all lanes that got an env, whatever chunks they came from
     }
 
-    // Population mode of the FNN kernel: a wave runs one policy at a time, whose weight image it keeps in LDS.
-    // Task q = (policy q / groups, rollouts 64 (q % groups) ... of that policy); the wave takes the next task when none
-    // of its lanes has an env.  Returns the policy of the wave; *fresh: a new task was taken (the caller loads its
-    // weight image).
-    PSH_DEV int turnover_wave(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol, bool* fresh) {
-        *fresh = false;
+    // Population mode of the FNN kernel: the 16 lanes of an MFMA tile share the A operand, i.e. the policy.  The lanes
+    // of a wave form groups of G = a.pop_tiles tiles (16, 32 or 64 lanes); a group runs one policy at a time, whose
+    // weight image the wave keeps in LDS.  Task q = (policy q / chunks, rollouts 16 G (q % chunks) ... of that policy);
+    // a group takes the next task when none of its lanes has an env.  Returns the policy of this lane's group;
+    // *fresh has the bit of a group's first lane set if the group took a new task (the caller loads its weight image).
+    PSH_DEV int turnover_group(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol,
+                               unsigned long long* fresh) {
         if (i >= 0 && !live) { store(a, wrap); i = -1; }
-        if (!__any(i >= 0) && !exhausted) {  // `exhausted` is set for all lanes together
-            const int lane = threadIdx.x & 63;
-            const int R = a.pol.policy_group, groups = (R + 63) / 64;
+        const int lane = threadIdx.x & 63, GL = 16 * a.pop_tiles;
+        const int first = lane & ~(GL - 1);
+        const unsigned long long busy = __ballot(i >= 0);
+        const unsigned long long group = (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)) << first;
+        bool got = false;
+        if ((busy & group) == 0 && !exhausted) {  // the same for all lanes of a group
+            const int R = a.pol.policy_group, chunks = (R + GL - 1) / GL;
             unsigned int q = 0;
-            if (lane == 0) q = atomicAdd(a.queue, 1u);
-            q = __builtin_amdgcn_readfirstlane(q);
-            if (q < (unsigned int)(a.pol.n_policies * groups)) {
-                pol = (int)(q / groups);
-                const int r = 64 * (int)(q % groups) + lane;
+            if (lane == first) q = atomicAdd(a.queue, 1u);
+            q = __shfl(q, first);
+            if (q < (unsigned int)(a.pol.n_policies * chunks)) {
+                pol = (int)(q / chunks);
+                const int r = GL * (int)(q % chunks) + (lane - first);
                 if (r < R) { i = (long)pol * R + r; load(a, task, wrap); }
-                *fresh = true;
+                got = lane == first;
             } else {
                 exhausted = true;
             }
         }
+        *fresh = __ballot(got);
         return pol;
     }
 
@@ -612,12 +619,14 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    // POP (population mode): every wave has a weight image of its own in LDS, that of the policy whose rollouts it
-    // runs (streamed from global memory per MFMA fragment the weights cost several microseconds of latency per layer:
-    // 100 us per step against 4)
+    // POP (population mode): every wave has weight images of its own in LDS, those of the policies whose rollouts its
+    // groups of tiles run (streamed from global memory per MFMA fragment the weights cost several microseconds of
+    // latency per layer: 100 us per step against 4)
     const int n_waves = (int)(blockDim.x >> 6);
-    const int w_doubles = POP ? n_waves * a.lds_doubles : a.lds_doubles;
-    double* const w_lds = lds + (POP ? wave * a.lds_doubles : 0);
+    const int pop_shift = a.pop_tiles >> 1;     // log2 of 1, 2, 4
+    const int imgs = POP ? 4 >> pop_shift : 1;  // images per wave
+    const int w_doubles = POP ? n_waves * imgs * a.lds_doubles : a.lds_doubles;
+    double* const w_lds = lds + (POP ? wave * imgs * a.lds_doubles : 0);
     double* const stage = lds + w_doubles + wave * (OP * 64);
     double* const tanh_tab = lds + w_doubles + n_waves * (OP * 64);
     double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
@@ -636,18 +645,22 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     L.init();
 
     const int n_hidden = a.pol.n_hidden;
-    int pol = 0;  // POP: policy of this wave
+    int pol = 0;  // POP: policy of this lane's group of tiles
     for (;;) {
         if constexpr (POP) {
-            bool fresh;
-            pol = L.turnover_wave(a, task, wrap, pol, &fresh);
-            if (fresh) {  // wave-uniform.  Only this wave reads or writes its image, in program order
-                const double* src = a.wfrag + (long)pol * a.lds_doubles;
-                for (int j = lane; j < a.lds_doubles; j += 64) w_lds[j] = src[j];
+            unsigned long long fresh;
+            pol = L.turnover_group(a, task, wrap, pol, &fresh);
+            if (fresh) {  // only this wave reads or writes its images, in program order
+                while (fresh) {
+                    const int first = __ffsll((long long)fresh) - 1;
+                    fresh &= fresh - 1;
+                    const double* src = a.wfrag + (long)__shfl(pol, first) * a.lds_doubles;
+                    double* dst = w_lds + (first >> (4 + pop_shift)) * a.lds_doubles;
+                    for (int j = lane; j < a.lds_doubles; j += 64) dst[j] = src[j];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (!__any(L.i >= 0)) continue;  // a task without rollouts
             }
         } else {
             L.turnover(a, task, wrap);
@@ -692,7 +705,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
             // nobody in this tile needs an action: skip it (the drain at the end of a launch, when few long episodes
             // are left, then costs a quarter per step; population tasks with fewer than 64 rollouts)
             if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;
-            const double* const wimg = w_lds;  // weight image of this wave's policy
+            const double* const wimg = POP ? w_lds + (tile >> pop_shift) * a.lds_doubles : w_lds;  // of this tile's policy
             double y[KS];
             // layer 0
             {
@@ -970,27 +983,35 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const bool fits12 = ((size_t)total + 12 * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
     const int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
     if (per_env) {
-        // population: one policy per wave, its weight image in LDS next to the wave's staging area; as many waves per
-        // workgroup as fit (the coarse tanh table if that makes room for one more)
-        const size_t per_wave = ((size_t)total + OP * 64) * sizeof(double);
+        // population: the tiles of a wave in groups of G, one policy per group, the weight images of a wave's groups in
+        // LDS next to its staging area.  G = 1, 2, 4 from the rollouts per policy (a group holds up to 16 G of them),
+        // waves per workgroup W and tanh table chosen for the most policies resident per CU; among equals fewer,
+        // fuller waves (the environment step costs a wave the same with 16 or 64 busy lanes), then the fine table.
         const size_t fixed_fine = ((size_t)TASK_DOUBLES + TANH8_PAD) * sizeof(double);
         const size_t fixed_coarse = ((size_t)TASK_DOUBLES + TANH_TAB_PAD) * sizeof(double);
-        const long groups = (p.policy_group + 63) / 64, tasks = (long)p.n_policies * groups;
-        auto waves_for = [&](size_t fixed) {
-            long w = c->lds_per_block > fixed ? (long)((c->lds_per_block - fixed) / per_wave) : 0;
-            return w > 8 ? 8 : w;
-        };
-        const long w_fine = waves_for(fixed_fine), w_coarse = waves_for(fixed_coarse);
-        const bool fine = w_fine >= w_coarse;
-        long W = fine ? w_fine : w_coarse;
+        const int g_min = p.policy_group > 32 ? 4 : (p.policy_group > 16 ? 2 : 1);
+        long W = 0, best = 0;
+        int G = 4;
+        bool fine = true;
+        for (int g = g_min; g <= 4; g *= 2) {
+            const size_t per_wave = ((size_t)(4 / g) * total + OP * 64) * sizeof(double);
+            for (int f = 1; f >= (HP == 64 ? 0 : 1); --f) {  // the narrower kernels exist with the fine table only
+                const size_t fixed = f ? fixed_fine : fixed_coarse;
+                long w = c->lds_per_block > fixed ? (long)((c->lds_per_block - fixed) / per_wave) : 0;
+                w = w > 8 ? 8 : w;
+                if (w * (4 / g) > best) { best = w * (4 / g); W = w; G = g; fine = f != 0; }
+            }
+        }
         if (W < 1) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
+        const long GL = 16 * G, tasks = (long)p.n_policies * ((p.policy_group + GL - 1) / GL);
         // no more waves per workgroup than keep every CU busy
-        while (W > 1 && tasks < (long)c->num_cus * W) W -= 1;
+        while (W > 1 && tasks < (long)c->num_cus * W * (4 / G)) W -= 1;
         const int BLOCK_POP = 64 * (int)W;
+        a.pop_tiles = G;
         a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
         a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
-        const size_t lds_pop = (size_t)W * per_wave + (fine ? fixed_fine : fixed_coarse);
-        const long lanes = tasks * 64;
+        const size_t lds_pop = (size_t)W * ((size_t)(4 / G) * total + OP * 64) * sizeof(double) + (fine ? fixed_fine : fixed_coarse);
+        const long lanes = (tasks + 4 / G - 1) / (4 / G) * 64;
 #define PSH_LAUNCH_POP(HP_, FINE_, TANH_)                                                                                \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))

@@ -385,7 +385,8 @@ def test_population_mode(eng, orc, policy, R):
     """ ParameterExplorationSampler's layout: env j*R + r runs parameter set j.  For FNN policies a wave runs one policy
     at a time (its weights in LDS), up to 64 of its rollouts: R below, at and above an MFMA tile and above a wave. """
     kind, pop = abi.ENV_QCP_ST, 37
-    kw = dict(hidden=(64, 32)) if policy == 'fnn' else {}
+    # the widest layer decides how many weight images fit into LDS, and with that how the tiles of a wave are shared out
+    kw = dict(hidden={1: (64, 32), 8: (16, 16), 16: (32, 20), 20: (16, 8), 70: (64, 64, 64), 130: (30,)}[R]) if policy == 'fnn' else {}
     case = cases.make_case(kind, pop*R, seed=13, policy=policy, **kw)
     params = 0.5*np.random.default_rng(2).standard_normal((pop, case['ps'].num_param))
     kwr = dict(policy_group=R, record=True)
