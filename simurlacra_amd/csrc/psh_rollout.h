@@ -995,7 +995,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         bool fine = true;
         for (int g = g_min; g <= 4; g *= 2) {
             const size_t per_wave = ((size_t)(4 / g) * total + OP * 64) * sizeof(double);
-            for (int f = 1; f >= (HP == 64 ? 0 : 1); --f) {  // the narrower kernels exist with the fine table only
+            for (int f = 1; f >= (HP >= 32 ? 0 : 1); --f) {  // the 16-wide kernels exist with the fine table only
                 const size_t fixed = f ? fixed_fine : fixed_coarse;
                 long w = c->lds_per_block > fixed ? (long)((c->lds_per_block - fixed) / per_wave) : 0;
                 w = w > 8 ? 8 : w;
@@ -1016,7 +1016,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
         if (HP == 16) return all_tanh ? PSH_LAUNCH_POP(16, true, true) : PSH_LAUNCH_POP(16, true, false);
-        if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, true, true) : PSH_LAUNCH_POP(32, true, false);
+        if (HP == 32 && fine) return all_tanh ? PSH_LAUNCH_POP(32, true, true) : PSH_LAUNCH_POP(32, true, false);
+        if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, false, true) : PSH_LAUNCH_POP(32, false, false);
         if (fine) return all_tanh ? PSH_LAUNCH_POP(64, true, true) : PSH_LAUNCH_POP(64, true, false);
         return all_tanh ? PSH_LAUNCH_POP(64, false, true) : PSH_LAUNCH_POP(64, false, false);
 #undef PSH_LAUNCH_POP
