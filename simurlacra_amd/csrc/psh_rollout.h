@@ -1006,11 +1006,13 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         const long GL = 16 * G, tasks = (long)p.n_policies * ((p.policy_group + GL - 1) / GL);
         // no more waves per workgroup than keep every CU busy
         while (W > 1 && tasks < (long)c->num_cus * W * (4 / G)) W -= 1;
+        const size_t waves_bytes = (size_t)W * ((size_t)(4 / G) * total + OP * 64) * sizeof(double);
+        fine = fine || waves_bytes + fixed_fine <= c->lds_per_block;  // fewer waves may leave room for the fine table
         const int BLOCK_POP = 64 * (int)W;
         a.pop_tiles = G;
         a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
         a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
-        const size_t lds_pop = (size_t)W * ((size_t)(4 / G) * total + OP * 64) * sizeof(double) + (fine ? fixed_fine : fixed_coarse);
+        const size_t lds_pop = waves_bytes + (fine ? fixed_fine : fixed_coarse);
         const long lanes = (tasks + 4 / G - 1) / (4 / G) * 64;
 #define PSH_LAUNCH_POP(HP_, FINE_, TANH_)                                                                                \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \

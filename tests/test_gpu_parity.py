@@ -407,14 +407,19 @@ def test_population_mode(eng, orc, policy, R):
     assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
 
 
-def test_large_fnn_population(eng, orc):
-    """ more tasks than resident waves: waves take over new (policy, group of rollouts) tasks and reload their weights """
-    kind, pop, R = abi.ENV_OMO, 3000, 4
-    case = cases.make_case(kind, pop*R, seed=3, policy='fnn', hidden=(16,))
-    params = 0.5*np.random.default_rng(5).standard_normal((pop, case['ps'].num_param))
+@pytest.mark.parametrize('kind,pop,R,hidden', [(abi.ENV_OMO, 3000, 4, (16,)), (abi.ENV_QQ, 800, 4, (64, 64)),
+                                               (abi.ENV_QCP_ST, 3100, 2, (32, 32)), (abi.ENV_QQ, 800, 40, (64,))],
+                         ids=['16-wide', '64-wide', '32-wide', '64-wide-R40'])
+def test_large_fnn_population(eng, orc, kind, pop, R, hidden):
+    """ Populations large enough for workgroups of several waves (for the 32- and 64-wide nets that is the layout with the
+    coarse tanh table) and, in the first case, more tasks than resident groups of tiles: groups take over new
+    (policy, chunk of rollouts) tasks and the wave reloads their weight images. """
+    case = cases.make_case(kind, pop*R, seed=3, policy='fnn', hidden=hidden, scale=0.3)
+    params = 0.3*np.random.default_rng(5).standard_normal((pop, case['ps'].num_param))
     ref = orc.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, case['init'], case['dp'], policy_group=R)
     out = eng.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, case['init'], case['dp'], policy_group=R)
     np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
     assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
 
 
