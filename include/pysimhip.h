@@ -18,6 +18,8 @@
  *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
  *    the library never synchronises the device except in psh_destroy.
  *  - one psh_ctx per (device, host thread).  A ctx is not thread-safe; distinct ctxs are independent.
+ *    The rollouts of one ctx share its scratch buffers: the library orders them on the device (a rollout issued on
+ *    another stream waits for the previous rollout of the same ctx), so one rollout per ctx runs at a time.
  *  - NaN never aborts a kernel: the per-env `status` word carries PSH_ST_NAN and the host layer raises
  *    the reference's ValueErr (Pyrado/pyrado/sampling/rollout.py:141-147,187-193).
  */
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 107
+#define PSH_VERSION 108
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -278,7 +280,7 @@ typedef struct psh_rollout_desc {
     const double* domain_param; /* [dev] */
     const int32_t* dp_index;    /* [dev] or NULL */
     int32_t ld_dp;
-    int32_t pad_;
+    int32_t dp_rows;            /* rows of domain_param; 0 = exactly the simulation's P.  wrap.act_delay_row must be below it */
     psh_task task;
     psh_policy policy;
     psh_wrappers wrap;          /* [host] fused environment wrappers; all-zero = none */

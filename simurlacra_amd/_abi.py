@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 107
+PSH_VERSION = 108
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -80,7 +80,7 @@ class PshRolloutDesc(C.Structure):
         ('env_kind', C.c_int32), ('n_envs', C.c_int32), ('max_steps', C.c_int32), ('flags', C.c_int32),
         ('dt', C.c_double),
         ('init_state', C.c_void_p), ('init_dim', C.c_int32), ('ld_init', C.c_int32),
-        ('domain_param', C.c_void_p), ('dp_index', C.c_void_p), ('ld_dp', C.c_int32), ('pad_', C.c_int32),
+        ('domain_param', C.c_void_p), ('dp_index', C.c_void_p), ('ld_dp', C.c_int32), ('dp_rows', C.c_int32),
         ('task', PshTask), ('policy', PshPolicy), ('wrap', PshWrappers), ('bernoulli_reset', C.c_double),
         ('ret', C.c_void_p), ('length', C.c_void_p), ('status', C.c_void_p), ('final_state', C.c_void_p),
         ('obs', C.c_void_p), ('act', C.c_void_p), ('rew', C.c_void_p),

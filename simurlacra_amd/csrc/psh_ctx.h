@@ -24,6 +24,10 @@ struct psh_ctx {
     size_t lds_per_block;
     hipEvent_t ev0, ev1;
     int timed;
+    // Every rollout of a context uses the context's scratch (queue counter, weight image, plate angles, delay rings):
+    // a rollout issued on another stream waits for this event, recorded behind the previous rollout's kernel.
+    hipEvent_t ev_done;
+    int have_done;
 };
 
 // grow-only device scratch owned by the context
@@ -47,6 +51,16 @@ static inline int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t 
     PSH_HIP(c, hipMalloc(buf, need * sizeof(double)));
     *have = need;
     return PSH_OK;
+}
+
+// The scratch buffers of a rollout, grown in the context.
+enum psh_scratch_kind { PSH_SCR_WFRAG = 0, PSH_SCR_PLATE = 1, PSH_SCR_DELAY = 2 };
+static inline int scratch_doubles(psh_ctx* c, int which, size_t need, double** out) {
+    if (which == PSH_SCR_WFRAG) { const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, need); *out = c->wfrag; return rc; }
+    if (which == PSH_SCR_PLATE) { const int rc = ensure_doubles(c, &c->plate, &c->plate_doubles, need); *out = c->plate; return rc; }
+    const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, need);
+    *out = c->delay_q;
+    return rc;
 }
 
 // Persistent launch: as many workgroups as the device keeps resident (lanes pull envs from the queue), fewer when the

@@ -874,9 +874,8 @@ static inline int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_
     const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, work_lanes < 0 ? (long)a.n_envs : work_lanes);
     a.n_lanes = (long)grid * block;
     if (need_delay_q) {
-        const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes);
+        const int rc = scratch_doubles(c, PSH_SCR_DELAY, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes, &a.delay_q);
         if (rc != PSH_OK) return rc;
-        a.delay_q = c->delay_q;
     }
     if (c->timed) PSH_HIP(c, hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, st, a);
@@ -964,15 +963,16 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
     const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = E::O / 4, REM = E::O % 4;
     const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
+    double* wfrag = nullptr;
     {
-        const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, (size_t)total * (per_env ? p.n_policies : 1));
+        const int rc = scratch_doubles(c, PSH_SCR_WFRAG, (size_t)total * (per_env ? p.n_policies : 1), &wfrag);
         if (rc != PSH_OK) return rc;
     }
     hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256, per_env ? p.n_policies : 1), dim3(256), 0, st, p.params,
-                       c->wfrag, total, Oe, (int)E::A, HP, K0, REM, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
+                       wfrag, total, Oe, (int)E::A, HP, K0, REM, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
                        p.num_param);
     PSH_HIP(c, hipGetLastError());
-    a.wfrag = c->wfrag;
+    a.wfrag = wfrag;
     a.lds_doubles = total;
     // 8 waves per workgroup (2 per SIMD) or 12 (3 per SIMD, which the 168 registers of the bare kernels allow).  The third
     // wave hides more latency (+2..9 % throughput while the queue lasts), but every wave then steps 1.5 times slower,
@@ -1033,6 +1033,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
 #define PSH_LAUNCH_FNN(HP_, FINE_, TANH_)                                                                                \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false, TANH_>, BLOCK, lds_bytes, a, E::A, has_delay, st) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false, TANH_>, BLOCK, lds_bytes, a, E::A, false, st))
+    // the narrower kernels exist with the fine table only (on gfx950 their weight images always leave room for it)
+    if (HP <= 32 && !fine) { set_err(c, "no LDS for the tanh table of this FNNPolicy"); return PSH_ERR_UNSUPPORTED; }
     if (HP == 16) return all_tanh ? PSH_LAUNCH_FNN(16, true, true) : PSH_LAUNCH_FNN(16, true, false);
     if (HP == 32) return all_tanh ? PSH_LAUNCH_FNN(32, true, true) : PSH_LAUNCH_FNN(32, true, false);
     if (fine) return all_tanh ? PSH_LAUNCH_FNN(64, true, true) : PSH_LAUNCH_FNN(64, true, false);

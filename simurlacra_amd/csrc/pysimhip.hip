@@ -307,6 +307,7 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
     const size_t tab_bytes = tab_n * sizeof(double);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, tab_bytes) != hipSuccess ||
         hipMemcpy(c->tanh_tab, tab.get(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
         psh_destroy(c);  // releases whatever was created before the failure
@@ -327,6 +328,7 @@ extern "C" void psh_destroy(psh_ctx* c) {
     if (c->tanh_tab) (void)hipFree(c->tanh_tab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     delete c;
 }
 
@@ -349,7 +351,41 @@ static int check_task(psh_ctx* c, const psh_task& t, int S) {
     return PSH_OK;
 }
 
-extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
+static int rollout_issue(psh_ctx* c, const psh_rollout_desc* d, hipStream_t st) {
+    int32_t dm[5];
+    dims_of(d->env_kind, dm);
+    RolloutArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
+    a.init_state = d->init_state; a.ld_init = d->ld_init;
+    a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
+    a.task = d->task; a.wrap = d->wrap; a.pol = d->policy; a.bernoulli = d->bernoulli_reset;
+    a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
+    a.obs = d->obs; a.act = d->act; a.rew = d->rew;
+    c->timed = 1;
+    a.queue = c->queue;
+    PSH_HIP(c, hipMemsetAsync(a.queue, 0, 256, st));
+    if (d->env_kind == PSH_ENV_QBB && !(d->flags & PSH_F_SIMPLIFIED_DYN)) {
+        double* plate = nullptr;
+        const int rc = scratch_doubles(c, PSH_SCR_PLATE, 2 * (size_t)d->n_envs, &plate);
+        if (rc != PSH_OK) return rc;
+        hipLaunchKernelGGL(k_qbb_plate, dim3((d->n_envs + 255) / 256), dim3(256), 0, st, a, plate);
+        PSH_HIP(c, hipGetLastError());
+        a.plate = plate;
+    }
+    switch (d->env_kind) {
+    case PSH_ENV_QQ: return launch_rollout<PSH_ENV_QQ>(c, d, a, st);
+    case PSH_ENV_QCP_SU: return launch_rollout<PSH_ENV_QCP_SU>(c, d, a, st);
+    case PSH_ENV_QCP_ST: return launch_rollout<PSH_ENV_QCP_ST>(c, d, a, st);
+    case PSH_ENV_QBB: return launch_rollout<PSH_ENV_QBB>(c, d, a, st);
+    case PSH_ENV_BOB: return launch_rollout<PSH_ENV_BOB>(c, d, a, st);
+    case PSH_ENV_PEND: return launch_rollout<PSH_ENV_PEND>(c, d, a, st);
+    case PSH_ENV_QQ_ST: return launch_rollout<PSH_ENV_QQ_ST>(c, d, a, st);
+    default: return launch_rollout<PSH_ENV_OMO>(c, d, a, st);
+    }
+}
+
+static int rollout_checked(psh_ctx* c, const psh_rollout_desc* d) {
     if (!c || !d) return PSH_ERR_ARG;
     int32_t dm[5];
     if (!dims_of(d->env_kind, dm)) { set_err(c, "unknown env_kind"); return PSH_ERR_ARG; }
@@ -363,39 +399,27 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) {
     if (!(d->init_dim == dm[4] || full_state)) { set_err(c, "init_dim must be the init-space or the state dimension"); return PSH_ERR_ARG; }
     if (d->ld_init < d->n_envs || d->ld_dp < 1 || (!d->dp_index && d->ld_dp < d->n_envs)) { set_err(c, "leading dimensions too small"); return PSH_ERR_ARG; }
     if (d->policy.n_policies < 1) { set_err(c, "n_policies must be >= 1"); return PSH_ERR_ARG; }
+    const int dp_rows = d->dp_rows > 0 ? d->dp_rows : dm[3];
+    if (dp_rows < dm[3]) { set_err(c, "dp_rows is smaller than the simulation's number of domain parameters"); return PSH_ERR_ARG; }
+    for (int j = 0; j < d->wrap.n_ops && j < PSH_MAX_WRAP; ++j) {
+        if (d->wrap.ops[j] == PSH_WRAP_ACT_DELAY && d->wrap.act_delay_row >= dp_rows) {
+            set_err(c, "act_delay_row outside the domain-parameter table (dp_rows)");
+            return PSH_ERR_ARG;
+        }
+    }
     int rc = check_task(c, d->task, dm[0]);
     if (rc != PSH_OK) return rc;
     PSH_HIP(c, hipSetDevice(c->device));
-    RolloutArgs a;
-    memset(&a, 0, sizeof a);
-    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
-    a.init_state = d->init_state; a.ld_init = d->ld_init;
-    a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
-    a.task = d->task; a.wrap = d->wrap; a.pol = d->policy; a.bernoulli = d->bernoulli_reset;
-    a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
-    a.obs = d->obs; a.act = d->act; a.rew = d->rew;
     hipStream_t st = (hipStream_t)d->stream;
-    c->timed = 1;
-    a.queue = c->queue;
-    PSH_HIP(c, hipMemsetAsync(c->queue, 0, 256, st));
-    if (d->env_kind == PSH_ENV_QBB && !(d->flags & PSH_F_SIMPLIFIED_DYN)) {
-        rc = ensure_doubles(c, &c->plate, &c->plate_doubles, 2 * (size_t)d->n_envs);
-        if (rc != PSH_OK) return rc;
-        hipLaunchKernelGGL(k_qbb_plate, dim3((d->n_envs + 255) / 256), dim3(256), 0, st, a, c->plate);
-        PSH_HIP(c, hipGetLastError());
-        a.plate = c->plate;
-    }
-    switch (d->env_kind) {
-    case PSH_ENV_QQ: return launch_rollout<PSH_ENV_QQ>(c, d, a, st);
-    case PSH_ENV_QCP_SU: return launch_rollout<PSH_ENV_QCP_SU>(c, d, a, st);
-    case PSH_ENV_QCP_ST: return launch_rollout<PSH_ENV_QCP_ST>(c, d, a, st);
-    case PSH_ENV_QBB: return launch_rollout<PSH_ENV_QBB>(c, d, a, st);
-    case PSH_ENV_BOB: return launch_rollout<PSH_ENV_BOB>(c, d, a, st);
-    case PSH_ENV_PEND: return launch_rollout<PSH_ENV_PEND>(c, d, a, st);
-    case PSH_ENV_QQ_ST: return launch_rollout<PSH_ENV_QQ_ST>(c, d, a, st);
-    default: return launch_rollout<PSH_ENV_OMO>(c, d, a, st);
-    }
+    // one rollout of a context at a time: its scratch is shared, so a launch on another stream waits for the last one
+    if (c->have_done) PSH_HIP(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    rc = rollout_issue(c, d, st);
+    // recorded also after a failure: whatever was enqueued before it (memset, prologue) may still touch the scratch
+    if (hipEventRecord(c->ev_done, st) == hipSuccess) c->have_done = 1;
+    return rc;
 }
+
+extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) { return rollout_checked(c, d); }
 
 extern "C" float psh_last_rollout_ms(psh_ctx* c) {
     if (!c || !c->timed) return -1.f;

@@ -123,6 +123,7 @@ class Engine:
         d.env_kind, d.n_envs, d.max_steps, d.flags, d.dt = env_kind, N, T, flags, float(dt)
         d.init_state, d.init_dim, d.ld_init = _ptr(init_state), init_state.shape[0], N
         d.domain_param, d.dp_index, d.ld_dp = _ptr(domain_param), _ptr(dp_index), domain_param.shape[1]
+        d.dp_rows = domain_param.shape[0]
         if wrap is not None:
             d.wrap = wrap.to_c(O, A)
         d.bernoulli_reset = float(bernoulli_reset)
