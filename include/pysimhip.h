@@ -299,6 +299,20 @@ typedef struct psh_rollout_desc {
 } psh_rollout_desc;
 int psh_rollout(psh_ctx* ctx, const psh_rollout_desc* desc);
 
+/* psh_rollout for callers that cannot allocate device memory.  No counterpart in the reference: it exists for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same descriptor, same kernels and
+ * bit-identical results, but the scratch of the launch (work-queue counter, packed FNN weights, QBallBalancer plate
+ * angles) lives in a static device array of the library (about 8.1 MiB per GPU, held until the process ends) instead
+ * of context-owned allocations, and the call itself performs no hipMalloc / hipFree.  Limits, rejected with
+ * PSH_ERR_UNSUPPORTED and a message: the packed weights of all policies of the call at most
+ * PSH_STATIC_MAX_WEIGHT_DOUBLES doubles (any single FNN the kernels support fits; a population of 64x64 networks up to
+ * about 3), QBallBalancerSim with the full dynamics at most PSH_STATIC_MAX_QBB_ENVS environments, no fused
+ * ActDelayWrapper (its ring buffers scale with the launch).  All calls on one GPU share the array, whatever their
+ * context: calls that overlap in time on one GPU race; calls of one context are ordered by the library. */
+#define PSH_STATIC_MAX_WEIGHT_DOUBLES 16384
+#define PSH_STATIC_MAX_QBB_ENVS 524288
+int psh_rollout_static(psh_ctx* ctx, const psh_rollout_desc* desc);
+
 /* ---- single steps for arbitrary (non-fusable) policies ---------------------------------------
  * psh_reset replaces SimPyEnv.reset (pysim/base.py:119-156) for N envs: state from init_state,
  * QBB plate angles by IK, step counter 0, first observation.

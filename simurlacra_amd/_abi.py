@@ -16,6 +16,8 @@ PSH_MAX_LIN_FEAT = 512
 PSH_MAX_DISTR = 32
 PSH_MAX_DELAY = 32
 PSH_MAX_WRAP = 6
+PSH_STATIC_MAX_WEIGHT_DOUBLES = 16384
+PSH_STATIC_MAX_QBB_ENVS = 524288
 
 PSH_OK, PSH_ERR_ARG, PSH_ERR_HIP, PSH_ERR_NODEV, PSH_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -133,6 +135,7 @@ PSH_SYMBOLS = {
     'psh_last_error': (C.c_char_p, [C.c_void_p]),
     'psh_env_dims': (C.c_int, [C.c_int, C.POINTER(C.c_int32*5)]),
     'psh_rollout': (C.c_int, [C.c_void_p, C.POINTER(PshRolloutDesc)]),
+    'psh_rollout_static': (C.c_int, [C.c_void_p, C.POINTER(PshRolloutDesc)]),
     'psh_reset': (C.c_int, [C.c_void_p, C.POINTER(PshStepDesc)]),
     'psh_step': (C.c_int, [C.c_void_p, C.POINTER(PshStepDesc)]),
     'psh_randomize': (C.c_int, [C.c_void_p, C.POINTER(PshRandDesc)]),

@@ -28,7 +28,17 @@ struct psh_ctx {
     // a rollout issued on another stream waits for this event, recorded behind the previous rollout's kernel.
     hipEvent_t ev_done;
     int have_done;
+    // psh_rollout_static: device address of the library's file-scope scratch array on this context's device, and
+    // whether the call being issued takes its scratch from there (it then allocates nothing)
+    unsigned char* static_scratch;
+    int static_mode;
 };
+
+// Layout of the file-scope scratch array of psh_rollout_static (bytes): [queue counter][weight image][plate angles]
+#define PSH_STATIC_QUEUE_BYTES 256
+#define PSH_STATIC_WFRAG_DOUBLES ((size_t)PSH_STATIC_MAX_WEIGHT_DOUBLES)
+#define PSH_STATIC_PLATE_DOUBLES (2 * (size_t)PSH_STATIC_MAX_QBB_ENVS)
+#define PSH_STATIC_BYTES (PSH_STATIC_QUEUE_BYTES + 8 * (PSH_STATIC_WFRAG_DOUBLES + PSH_STATIC_PLATE_DOUBLES))
 
 // grow-only device scratch owned by the context
 static inline void set_err(psh_ctx* c, const char* fmt, const char* a = "", const char* b = "") {
@@ -53,9 +63,25 @@ static inline int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t 
     return PSH_OK;
 }
 
-// The scratch buffers of a rollout, grown in the context.
+// The scratch buffers of a rollout.  psh_rollout grows them in the context; psh_rollout_static hands out fixed regions of
+// the library's static array and rejects what does not fit.
 enum psh_scratch_kind { PSH_SCR_WFRAG = 0, PSH_SCR_PLATE = 1, PSH_SCR_DELAY = 2 };
 static inline int scratch_doubles(psh_ctx* c, int which, size_t need, double** out) {
+    if (c->static_mode) {
+        double* const base = reinterpret_cast<double*>(c->static_scratch + PSH_STATIC_QUEUE_BYTES);
+        if (which == PSH_SCR_WFRAG) {
+            if (need > PSH_STATIC_WFRAG_DOUBLES) { set_err(c, "psh_rollout_static: the packed policy weights exceed PSH_STATIC_MAX_WEIGHT_DOUBLES"); return PSH_ERR_UNSUPPORTED; }
+            *out = base;
+            return PSH_OK;
+        }
+        if (which == PSH_SCR_PLATE) {
+            if (need > PSH_STATIC_PLATE_DOUBLES) { set_err(c, "psh_rollout_static: more than PSH_STATIC_MAX_QBB_ENVS QBallBalancer environments with the full dynamics"); return PSH_ERR_UNSUPPORTED; }
+            *out = base + PSH_STATIC_WFRAG_DOUBLES;
+            return PSH_OK;
+        }
+        set_err(c, "psh_rollout_static: the fused ActDelayWrapper needs ring buffers sized by the launch; use psh_rollout");
+        return PSH_ERR_UNSUPPORTED;
+    }
     if (which == PSH_SCR_WFRAG) { const int rc = ensure_doubles(c, &c->wfrag, &c->wfrag_doubles, need); *out = c->wfrag; return rc; }
     if (which == PSH_SCR_PLATE) { const int rc = ensure_doubles(c, &c->plate, &c->plate_doubles, need); *out = c->plate; return rc; }
     const int rc = ensure_doubles(c, &c->delay_q, &c->delay_q_doubles, need);

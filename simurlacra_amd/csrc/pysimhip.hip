@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 
 #include "psh_rollout.h"
@@ -30,6 +31,27 @@ extern template int launch_rollout<PSH_ENV_BOB>(psh_ctx*, const psh_rollout_desc
 extern template int launch_rollout<PSH_ENV_OMO>(psh_ctx*, const psh_rollout_desc*, RolloutArgs&, hipStream_t);
 extern template int launch_rollout<PSH_ENV_PEND>(psh_ctx*, const psh_rollout_desc*, RolloutArgs&, hipStream_t);
 extern template int launch_rollout<PSH_ENV_QQ_ST>(psh_ctx*, const psh_rollout_desc*, RolloutArgs&, hipStream_t);
+
+// Scratch of psh_rollout_static, the entry point that allocates nothing: work-queue counter, packed policy weights
+// and QBallBalancer plate angles live in this array instead of context-owned allocations.  Every GPU the library runs
+// on holds its own copy for the life of the process.  Host code never uses the array's name as an address: psh_create
+// asks the runtime for the device address once per device (static_scratch_of) and everything else goes through that.
+static __device__ __align__(256) unsigned char scratch[PSH_STATIC_BYTES];
+
+static std::mutex g_scratch_lock;
+static unsigned char* g_scratch_ptr[64];  // per HIP device, filled with that device current
+
+static int static_scratch_of(psh_ctx* c) {
+    if (c->device < 0 || c->device >= 64) return PSH_ERR_NODEV;
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (!g_scratch_ptr[c->device]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PSH_ERR_HIP;
+        g_scratch_ptr[c->device] = static_cast<unsigned char*>(p);
+    }
+    c->static_scratch = g_scratch_ptr[c->device];
+    return PSH_OK;
+}
 
 // QBallBalancerSim.reset: plate angles of every env by inverse kinematics, ahead of the rollout kernel, so that a lane
 // taking over a new env only reads two numbers instead of running 200 optimiser steps while its wave waits.
@@ -307,7 +329,7 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
     const size_t tab_bytes = tab_n * sizeof(double);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess || static_scratch_of(c) != PSH_OK ||
         hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, tab_bytes) != hipSuccess ||
         hipMemcpy(c->tanh_tab, tab.get(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
         psh_destroy(c);  // releases whatever was created before the failure
@@ -363,8 +385,8 @@ static int rollout_issue(psh_ctx* c, const psh_rollout_desc* d, hipStream_t st) 
     a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
     a.obs = d->obs; a.act = d->act; a.rew = d->rew;
     c->timed = 1;
-    a.queue = c->queue;
-    PSH_HIP(c, hipMemsetAsync(a.queue, 0, 256, st));
+    a.queue = c->static_mode ? reinterpret_cast<unsigned int*>(c->static_scratch) : c->queue;
+    PSH_HIP(c, hipMemsetAsync(a.queue, 0, PSH_STATIC_QUEUE_BYTES, st));
     if (d->env_kind == PSH_ENV_QBB && !(d->flags & PSH_F_SIMPLIFIED_DYN)) {
         double* plate = nullptr;
         const int rc = scratch_doubles(c, PSH_SCR_PLATE, 2 * (size_t)d->n_envs, &plate);
@@ -385,7 +407,7 @@ static int rollout_issue(psh_ctx* c, const psh_rollout_desc* d, hipStream_t st) 
     }
 }
 
-static int rollout_checked(psh_ctx* c, const psh_rollout_desc* d) {
+static int rollout_checked(psh_ctx* c, const psh_rollout_desc* d, bool use_static) {
     if (!c || !d) return PSH_ERR_ARG;
     int32_t dm[5];
     if (!dims_of(d->env_kind, dm)) { set_err(c, "unknown env_kind"); return PSH_ERR_ARG; }
@@ -413,13 +435,17 @@ static int rollout_checked(psh_ctx* c, const psh_rollout_desc* d) {
     hipStream_t st = (hipStream_t)d->stream;
     // one rollout of a context at a time: its scratch is shared, so a launch on another stream waits for the last one
     if (c->have_done) PSH_HIP(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    c->static_mode = use_static ? 1 : 0;
     rc = rollout_issue(c, d, st);
+    c->static_mode = 0;
     // recorded also after a failure: whatever was enqueued before it (memset, prologue) may still touch the scratch
     if (hipEventRecord(c->ev_done, st) == hipSuccess) c->have_done = 1;
     return rc;
 }
 
-extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) { return rollout_checked(c, d); }
+extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) { return rollout_checked(c, d, false); }
+
+extern "C" int psh_rollout_static(psh_ctx* c, const psh_rollout_desc* d) { return rollout_checked(c, d, true); }
 
 extern "C" float psh_last_rollout_ms(psh_ctx* c) {
     if (!c || !c->timed) return -1.f;

@@ -94,12 +94,14 @@ class Engine:
     # -- fused rollouts
     def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *,
                 flags=abi.F_STOP_ON_DONE, dp_index=None, policy_index=None, policy_group=0, record=False,
-                wrap=None, bernoulli_reset=0., final_state=True, out=None):
+                wrap=None, bernoulli_reset=0., final_state=True, out=None, static_scratch=False):
         """ N fused rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]
         (device tensors, fp64).  Returns a dict of device tensors: ret [N], length [N], status [N], final_state [S, N]
         and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N].  `wrap` (a WrapSpec) fuses environment
         wrappers into the step loop; with an ObsPartialWrapper in it O is the number of kept observations.
-        policy_group = R > 0: population mode, env i runs params[i // R] (N = n_policies * R). """
+        policy_group = R > 0: population mode, env i runs params[i // R] (N = n_policies * R).
+        static_scratch: issue the launch through psh_rollout_static, which takes its scratch from the library's static
+        device array and allocates nothing (pass `out` as well to keep torch from allocating the results). """
         S, O, A, P, _ = abi.ENV_DIMS[env_kind]
         O_rec = O if wrap is None else wrap.obs_dim(O)
         init_state, domain_param = self.f64(init_state), self.f64(domain_param)
@@ -136,7 +138,10 @@ class Engine:
         d.final_state = _ptr(out.get('final_state'))
         d.obs, d.act, d.rew = _ptr(out.get('obs')), _ptr(out.get('act')), _ptr(out.get('rew'))
         d.stream = self._stream()
-        self._check(self.lib.psh_rollout(self._h, C.byref(d)), 'psh_rollout')
+        if static_scratch:
+            self._check(self.lib.psh_rollout_static(self._h, C.byref(d)), 'psh_rollout_static')
+        else:
+            self._check(self.lib.psh_rollout(self._h, C.byref(d)), 'psh_rollout')
         return out
 
     def last_rollout_ms(self) -> float:
