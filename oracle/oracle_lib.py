@@ -38,6 +38,8 @@ def lib():
         L.orc_sample_init.argtypes = [C.POINTER(abi.PshInitDesc)]
         L.orc_qbb_ik.restype = C.c_double
         L.orc_qbb_ik.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.orc_qbb_ik_n.restype = C.c_double
+        L.orc_qbb_ik_n.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, abi.c_double_p]
         L.orc_step_rew.restype = C.c_double
         L.orc_step_rew.argtypes = [C.c_int, C.POINTER(abi.PshTask), abi.c_double_p, abi.c_double_p, abi.c_double_p]
         L.orc_constants.restype = None
@@ -171,6 +173,13 @@ def sample_init(env_kind, n_envs, domain_param, seed, env_offset=0, dp_index=Non
 
 def qbb_ik(th, r_arm, l_plate):
     return lib().orc_qbb_ik(float(th), float(r_arm), float(l_plate))
+
+
+def qbb_ik_n(th, r_arm, l_plate, n_iter):
+    """ plate angle and rod tip after n_iter optimizer steps """
+    tip = np.zeros(2)
+    ang = lib().orc_qbb_ik_n(float(th), float(r_arm), float(l_plate), int(n_iter), tip.ctypes.data_as(abi.c_double_p))
+    return ang, tip
 
 
 def step_rew(env_kind, task_c, dp, state, act):

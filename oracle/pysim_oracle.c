@@ -10,7 +10,7 @@
  * are "parity unpinned": they are pinned only by restating the cited source lines expression by
  * expression (same operand order, no FMA contraction: build with -ffp-contract=off) and by a second,
  * independent NumPy restatement (oracle/pysim_oracle_np.py) that must agree to ~1 ulp.  The parts the
- * reference's tests DO pin with numbers are checked against those numbers in tests/test_oracle_kat.py:
+ * reference's tests DO pin with numbers are checked against those numbers in tests/test_oracle.py and tests/test_anchors.py:
  * radial-wrap reward (Pyrado/tests/test_tasks.py:44-61), FinalRewTask yields once (:181-188),
  * polar sampling (Pyrado/tests/test_spaces.py:145-154).
  *
@@ -243,11 +243,11 @@ static double final_rew(orc_env* e, const psh_task* t, int remaining) {
 
 /* QBallBalancerKin.__call__ pysim/quanser_ball_balancer.py:413-480; torch.optim.SGD(lr=0.01,
  * momentum=0.9) with the autograd chain of _loss_fcn written out */
-double orc_qbb_ik(double th, double r, double l_plate) {
+double orc_qbb_ik_n(double th, double r, double l_plate, int n_iter, double* tip_out) {
     const double l = l_plate / 2., d = 0.10;
     double t0 = r, t1 = l, b0 = 0., b1 = 0.;
     const double cx = r * cos(th), cy = r * sin(th);
-    for (int it = 0; it < 100; ++it) {
+    for (int it = 0; it < n_iter; ++it) {
         double dx1 = t0 - cx, dy1 = t1 - cy;
         double rod = sqrt(dx1 * dx1 + dy1 * dy1);
         double dx2 = t0 - r - l, dy2 = t1 - d;
@@ -260,8 +260,12 @@ double orc_qbb_ik(double th, double r, double l_plate) {
         t0 = t0 - 0.01 * b0;
         t1 = t1 - 0.01 * b1;
     }
+    if (tip_out) { tip_out[0] = t0; tip_out[1] = t1; }
     return ORC_PI / 2. - atan2(r + l - t0, t1 - d);
 }
+
+/* num_opt_iter = 100 is the constructor default nobody overrides (pysim/quanser_ball_balancer.py:385) */
+double orc_qbb_ik(double th, double r, double l_plate) { return orc_qbb_ik_n(th, r, l_plate, 100, 0); }
 
 /* SimPyEnv.reset pysim/base.py:119-156 (+ QBB reset pysim/quanser_ball_balancer.py:175-195) */
 static void env_reset(orc_env* e, const psh_task* t, const double* dp, const double* init, int init_dim) {
