@@ -430,3 +430,52 @@ def test_nan_raises_like_the_reference():
         rollout(env, pol, eval=True)
     with pytest.raises(pyrado.ValueErr):
         ParallelSampler(env, pol, 1, min_rollouts=4).sample()
+
+
+@pytest.mark.parametrize('policy', ['linear', 'fnn16', 'fnn64'])
+def test_cem_generation_on_randomized_qbb_matches_the_oracle(policy):
+    """ The CEM workload of BASELINE configs[3] as a caller writes it: QBallBalancerSim behind ActNormWrapper and
+    ActDelayWrapper, the default randomizer plus a per-rollout 'act_delay' drawn from {0..10}
+    (Pyrado/scripts/training/qbb_spota_hc.py:29-38), a population of 256 policy-parameter sets x 8 shared (domain
+    parameter, initial state) pairs through ParameterExplorationSampler.sample
+    (Pyrado/pyrado/sampling/parameter_exploration_sampler.py:171-201).  Returns, lengths, status words and the recorded
+    trajectories of all 2048 rollouts against the C oracle run on the sampler's own parameters and initial states. """
+    from oracle import oracle_lib as orc
+    from simurlacra_amd.domain_randomization import UniformDomainParam
+    from simurlacra_amd.sampling.batch import EnvPlan
+    T, pop, R = 150, 256, 8
+    env = ActDelayWrapper(ActNormWrapper(ENVS['qbb'](T)))
+    randomizer = get_default_randomizer(env)
+    randomizer.add_domain_params(UniformDomainParam(name='act_delay', mean=5, halfspan=5, clip_lo=0, roundint=True))
+    renv = DomainRandWrapperLive(env, randomizer)
+    gen = to.Generator().manual_seed(11)
+    if policy == 'linear':
+        pol = LinearPolicy(renv.spec, FeatureStack([identity_feat]))
+        sigma = 0.05
+    else:
+        h = 16 if policy == 'fnn16' else 64
+        pol = FNNPolicy(renv.spec, [h, h], to.tanh)
+        sigma = 0.02
+    theta0 = 0.05*to.randn(pol.num_param, dtype=to.float64, generator=gen)
+    param_sets = theta0 + sigma*to.randn((pop, pol.num_param), dtype=to.float64, generator=gen)   # theta ~ N(theta_0, sigma^2)
+    res = ParameterExplorationSampler(renv, pol, num_envs=1, num_rollouts_per_param=R, seed=3).sample(param_sets)
+    assert len(res) == pop and res.num_rollouts == pop*R
+    batch = res[0].rollouts
+    out = {k: v.cpu().numpy() for k, v in batch.device_results.items()}
+    dp, r_idx = batch._dp.cpu().numpy(), batch._dp_index.cpu().numpy()
+    assert dp.shape == (21, R) and np.array_equal(r_idx, np.tile(np.arange(R), pop))
+    delays = dp[20]
+    assert np.all(delays == np.round(delays)) and delays.min() >= 0 and delays.max() <= 10 and len(set(delays)) > 2
+    # common random numbers: rollout r of every parameter set starts from the same state under the same parameters
+    init = out['obs'][0]                                       # [8, pop*R]: QBallBalancerSim observes its state
+    assert np.array_equal(init, np.tile(init[:, :R], (1, pop)))
+    plan = EnvPlan(env)
+    ref = orc.rollout(abi.ENV_QBB, env.dt, T, plan.sim.task_spec().to_c(8, 2), pol.fused_spec(), param_sets.numpy(), init, dp,
+                      dp_index=r_idx, policy_group=R, record=True, wrap=plan.wrap_spec(0, 0))
+    np.testing.assert_array_equal(out['length'], ref['length'])
+    np.testing.assert_array_equal(out['status'], ref['status'])
+    errs = {k: cases.rel_err(out[k], ref[k]) for k in ('ret', 'obs', 'act', 'rew')}
+    assert max(errs.values()) <= TOL, errs
+    assert cases.rel_err(res.mean_returns, ref['ret'].reshape(pop, R).mean(axis=1)) <= TOL
+    if policy != 'linear':   # under the networks some balls leave the plate; the small linear gains keep all of them on it
+        assert ref['length'].min() < T and (ref['status'] & abi.ST_FAILED).any()
