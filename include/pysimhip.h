@@ -385,7 +385,8 @@ int psh_randomize(psh_ctx* ctx, const psh_rand_desc* desc);
  * BoxSpace (Pyrado/pyrado/spaces/box.py:133-142), Polar2DPosVelSpace (spaces/polar.py:64-69, QBB),
  * CompoundSpace of two boxes (spaces/compound.py:51-54, BOB).  The init spaces of BOB and QBB depend
  * on the env's own domain parameters (l_beam, l_plate), read from `domain_param`.
- * Philox keyed by (seed, env_offset + i), disjoint from the psh_randomize streams. */
+ * Philox keyed by (seed, env_offset + i) on a stream of its own: the same seed and offset may be handed to
+ * psh_randomize, psh_sample_init and the noise streams of psh_rollout without any two of them sharing a draw. */
 typedef struct psh_init_desc {
     int32_t env_kind;
     int32_t n_envs;

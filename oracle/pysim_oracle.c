@@ -979,7 +979,7 @@ int orc_sample_init(const psh_init_desc* d) {
         if (bad) col = 0;
         double lo[4], hi[4], u[5];
         uint64_t env = d->env_offset + (uint64_t)i;
-        for (int r = 0; r < 5; ++r) { double ub; draw2(d->seed, env, (uint32_t)r, 1u, &u[r], &ub); }
+        for (int r = 0; r < 5; ++r) { double ub; draw2(d->seed, env, (uint32_t)r, 5u, &u[r], &ub); } /* stream 5: initial states */
         switch (d->env_kind) {
         case PSH_ENV_QQ: {
             double m[4] = {2. / 180 * ORC_PI, 1. / 180 * ORC_PI, 0.5 / 180 * ORC_PI, 0.5 / 180 * ORC_PI};

@@ -27,6 +27,15 @@ __device__ __forceinline__ double psh_u01(uint32_t hi, uint32_t lo) {
     return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// Stream ids (counter word 3).  A sampler that draws several pairs per (env, row) uses stream + 16 p for pair p, so the
+// ids below 16 are disjoint for every p.  Callers may hand the same seed and env offset to all samplers.
+#define PSH_STREAM_RANDOMIZE 0u   // domain parameters, row = row of the table
+#define PSH_STREAM_OBS_NOISE 1u   // GaussianObsNoiseWrapper, row = step
+#define PSH_STREAM_ACT_NOISE 2u   // GaussianActNoiseWrapper, row = step
+#define PSH_STREAM_EXPL 3u        // action-noise exploration, row = step
+#define PSH_STREAM_BERNOULLI 4u   // stochastic reset, row = step
+#define PSH_STREAM_INIT 5u        // initial states, row = component
+
 // two uniforms for (seed, env, row, stream)
 __device__ __forceinline__ void psh_draw2(uint64_t seed, uint64_t env, uint32_t row, uint32_t stream, double& ua, double& ub) {
     const Philox4 o = philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), row, stream, (uint32_t)seed, (uint32_t)(seed >> 32));

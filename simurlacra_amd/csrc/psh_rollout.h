@@ -248,7 +248,7 @@ template <int KIND, bool WRAP> struct Lane {
             const int op = wrap.ops[j];
             if (op == PSH_WRAP_OBS_NOISE) {
                 double n[E::O];
-                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, t, 1u, n);
+                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, t, PSH_STREAM_OBS_NOISE, n);
 #pragma unroll
                 for (int r = 0; r < E::O; ++r) o[r] = o[r] + (n[r] * wrap.obs_noise_std[r] + wrap.obs_noise_mean[r]);
             } else if (op == PSH_WRAP_OBS_NORM) {
@@ -299,12 +299,12 @@ template <int KIND, bool WRAP> struct Lane {
             // replaces the policy's output for everything that follows
             if (a.pol.expl_kind == PSH_EXPL_NORMAL) {
                 double n[E::A];
-                step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, n);
+                step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, PSH_STREAM_EXPL, n);
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) act[r] = (act[r] + a.pol.expl_mean[r]) + n[r] * a.pol.expl_scale[r];
             } else if (a.pol.expl_kind == PSH_EXPL_UNIFORM) {
                 double u[2];
-                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 3u, u[0], u[1]);
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, PSH_STREAM_EXPL, u[0], u[1]);
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) {
                     const double m = act[r] + a.pol.expl_mean[r];
@@ -343,7 +343,7 @@ template <int KIND, bool WRAP> struct Lane {
                     for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
                 } else if (op == PSH_WRAP_ACT_NOISE) {
                     double n[E::A];
-                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, 2u, n);
+                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, PSH_STREAM_ACT_NOISE, n);
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
                 }
@@ -374,7 +374,7 @@ template <int KIND, bool WRAP> struct Lane {
         if constexpr (WRAP) {
             if (live && a.bernoulli > 0.) {  // stochastic reset (sampling/rollout.py:248-254)
                 double u0, u1;
-                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)(k - 1), 4u, u0, u1);
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)(k - 1), PSH_STREAM_BERNOULLI, u0, u1);
                 if (u0 < a.bernoulli) { st |= PSH_ST_BERNOULLI; live = false; }
             }
         }

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_randomize(const RandArgs a) {
     for (int k = 0; k < a.n_distr; ++k) {
         const psh_distr& d = a.distr[k];
         double ua, ub, x = d.a;
-        psh_draw2(a.seed, a.env_offset + (uint64_t)i, (uint32_t)d.row, 0u, ua, ub);
+        psh_draw2(a.seed, a.env_offset + (uint64_t)i, (uint32_t)d.row, PSH_STREAM_RANDOMIZE, ua, ub);
         if (d.kind == PSH_DISTR_NORMAL) {
             const double r = sqrt(-2.0 * log(1.0 - ua));
             x = d.a + d.b * (r * cos(2.0 * PSH_PI * ub));
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_sample_init(const InitArgs a) {
     const long col = dp_column(a.dp_index, a.ld_dp, i, &bad_index);
     double lo[4], hi[4], u[5], ub;
     const uint64_t env = a.env_offset + (uint64_t)i;
-    for (int r = 0; r < 5; ++r) psh_draw2(a.seed, env, (uint32_t)r, 1u, u[r], ub);
+    for (int r = 0; r < 5; ++r) psh_draw2(a.seed, env, (uint32_t)r, PSH_STREAM_INIT, u[r], ub);
     int I = 4;
     switch (a.env_kind) {
     case PSH_ENV_QQ: {

@@ -5,7 +5,6 @@ from .action_normalization import ActNormWrapper
 from .domain_randomization import (DomainRandWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive,
                                    MetaDomainRandWrapper, remove_all_dr_wrappers)
 from .observation_noise import GaussianObsNoiseWrapper
-from .downsampling import DownsamplingWrapper
-from .observation_normalization import ObsNormWrapper, ObsRunningNormWrapper, RunningNormalizer
+from .observation_normalization import ObsNormWrapper
 from .observation_partial import ObsPartialWrapper
 from .utils import all_envs, attr_env, attr_env_get, inner_env, remove_env, typed_env

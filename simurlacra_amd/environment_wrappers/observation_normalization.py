@@ -1,8 +1,6 @@
 """
 ObsNormWrapper (Pyrado/pyrado/environment_wrappers/observation_normalization.py:12-106): observations mapped
 affinely from the wrapped environment's observation bounds (optionally overridden per label) to [-1, 1].
-ObsRunningNormWrapper (:109-135) normalises with the bounds seen so far (RunningNormalizer,
-Pyrado/pyrado/utils/normalizing.py:7-84); its state spans rollouts, so it stays with the single-environment step loop.
 """
 from typing import Mapping, Optional
 
@@ -59,50 +57,3 @@ class ObsNormWrapper(EnvWrapperObs):
         lb_norm = (lb - lb_ov)/(ub_ov - lb_ov)*2 - 1
         ub_norm = (ub - lb_ov)/(ub_ov - lb_ov)*2 - 1
         return BoxSpace(lb_norm, ub_norm, labels=space.labels)
-
-
-class RunningNormalizer:
-    """ Maps data to [-1, 1] with the element-wise minimum / maximum of everything seen so far
-    (Pyrado/pyrado/utils/normalizing.py:7-84, the NumPy branch). """
-
-    def __init__(self):
-        self._bound_lo = None
-        self._bound_up = None
-        self.eps = 1e-3
-        self._iter = 0
-
-    def reset(self):
-        self._bound_lo = None
-        self._bound_up = None
-        self._iter = 0
-
-    def __call__(self, data: np.ndarray) -> np.ndarray:
-        data_2d = np.atleast_2d(data)
-        data_min, data_max = np.min(data_2d, axis=0), np.max(data_2d, axis=0)
-        self._iter += 1
-        if self._iter <= 1:
-            self._bound_lo, self._bound_up = data_min, data_max
-        else:
-            if not self._bound_lo.shape == data_min.shape:
-                from ..utils.exceptions import ShapeErr
-                raise ShapeErr(given=data_min, expected_match=self._bound_lo)
-            self._bound_lo = np.fmin(self._bound_lo, data_min)
-            self._bound_up = np.fmax(self._bound_up, data_max)
-        if np.linalg.norm(self._bound_up - self._bound_lo, ord=1) < self.eps:   # bounds must not collapse
-            self._bound_lo = self._bound_lo - self.eps/2
-            self._bound_up = self._bound_up + self.eps/2
-        return (data - self._bound_lo)/(self._bound_up - self._bound_lo)*2 - 1
-
-
-class ObsRunningNormWrapper(EnvWrapperObs):
-    def __init__(self, wrapped_env):
-        super().__init__(wrapped_env)
-        self.normalizer = RunningNormalizer()
-
-    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
-        return self.normalizer(obs)
-
-    def _process_obs_space(self, space: BoxSpace) -> BoxSpace:
-        if not isinstance(space, BoxSpace):
-            raise NotImplementedError('Only implemented ObsRunningNormWrapper._process_obs_space() for BoxSpace!')
-        return BoxSpace(-np.ones(space.shape), np.ones(space.shape), labels=space.labels)

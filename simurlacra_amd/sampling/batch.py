@@ -24,7 +24,7 @@ from ..environment_wrappers.domain_randomization import (DomainRandWrapper, Doma
 from ..environment_wrappers.utils import all_envs, inner_env
 from ..environments.pysim.base import SimPyEnv
 from ..specs import WrapSpec
-from ..utils.exceptions import ValueErr
+from ..utils.exceptions import TypeErr, ValueErr
 from .step_sequence import StepSequence
 
 
@@ -40,7 +40,8 @@ class EnvPlan:
         self.sim = inner_env(env)
         if not isinstance(self.sim, SimPyEnv):
             raise NotImplementedError(f'{type(self.sim).__name__} is not one of the simulations the rollout kernels '
-                                      f'implement (QQube, QCartPole, QBallBalancer, BallOnBeam, OneMassOscillator)')
+                                      f'implement (QQube, QQubeStab, QCartPoleSwingUp, QCartPoleStab, QBallBalancer, BallOnBeam, '
+                                      f'OneMassOscillator, Pendulum)')
         self.kind = self.sim.kind
         self.S, self.O, self.A, self.P, self.I = abi.ENV_DIMS[self.kind]
         self.dr_wrapper = None       # outermost DomainRandWrapperLive/Buffer (Meta wrappers forward to it)
@@ -136,32 +137,51 @@ class EnvPlan:
         return out
 
 
-def sample_domain_params(plan: EnvPlan, eng, n: int, seed: int, env_offset: int = 0):
+def sample_domain_params(plan: EnvPlan, eng, n: int, seed: int, env_offset: int = 0, n_global: int = None,
+                         shard_start: int = 0):
     """ Domain parameters for n environments as a device table [P (+1), M] plus an index [n] (or None when M == n).
     Live wrapper: drawn on the device from the randomizer's distributions (host torch.distributions only for
     distributions without a device sampler); buffer wrapper: the buffer is the table and the ring index advances by
     n; no wrapper: the environment's current parameters for every lane.  With an ActDelayWrapper in the chain the
-    table has one more row, the delay of each column (the domain parameter 'act_delay'). """
+    table has one more row, the delay of each column (the domain parameter 'act_delay').  Under torch.distributed a
+    rank passes the global count of this call as n_global and the index of its first rollout within it as shard_start. """
     w = plan.dr_wrapper
     nominal = plan.sim.domain_param_column()
     delay = [float(plan.delay_wrapper.delay)] if plan.delay_wrapper is not None else []
     column = plan.dp_column
     if w is None:
         return eng.f64(column().reshape(-1, 1)), torch.zeros(n, dtype=torch.int32, device=eng.device)
-    if isinstance(w, DomainRandWrapperBuffer) and w.buffer is not None:
+    if isinstance(w, DomainRandWrapperBuffer):
+        if w.buffer is None:
+            # DomainRandWrapperBuffer.reset (Pyrado/pyrado/environment_wrappers/domain_randomization.py:179-199) indexes
+            # the buffer: an unfilled one is an error there too
+            raise TypeErr(msg='The buffer of the DomainRandWrapperBuffer is empty: call fill_buffer() first!')
         buf = w.buffer if isinstance(w.buffer, list) else [w.buffer]
         table = np.stack([column(d) for d in buf], axis=1)
         start = w.ring_idx or 0
-        idx = (start + np.arange(n)) % len(buf)
-        w._ring_idx = int((start + n) % len(buf))
+        # the ring is indexed by the GLOBAL rollout index and advances by the global count, so every rank count
+        # replays the same entries
+        total = n if n_global is None else n_global
+        idx = (start + shard_start + np.arange(n)) % len(buf)
+        w._ring_idx = int((start + total) % len(buf))
         return eng.f64(table), eng.i32(idx)
     rand = w.randomizer
     try:
         distrs = rand.device_table(plan.names, plan.extra_rows)
     except NotImplementedError:
-        rand.randomize(n)
+        # no device sampler for one of the distributions: the host draws, from a generator seeded by the call's key,
+        # the whole global batch on every rank (identical everywhere), and each rank keeps its own columns
+        total = n if n_global is None else n_global
+        first = shard_start
+        state = torch.random.get_rng_state()
+        torch.manual_seed(int(seed) & 0x7fffffffffffffff)
+        try:
+            rand.randomize(total)
+        finally:
+            torch.random.set_rng_state(state)
         lst = rand.get_params(-1, format='list', dtype='numpy')
         lst = [lst] if isinstance(lst, dict) else lst
+        lst = lst[first:first + n]
         keys = list(plan.names) + plan.extra_rows
         return eng.f64(np.stack([column({k: float(v) for k, v in d.items() if k in keys}) for d in lst], axis=1)), None
     return eng.randomize(n, distrs, list(nominal) + delay, seed=seed, env_offset=env_offset), None
@@ -203,23 +223,32 @@ def run_batch(plan: EnvPlan, eng, policy, init_state, dp, dp_index=None, *, max_
 
 
 def _obs_bounds(plan, dp, dp_index, N):
-    """ Per-lane observation bounds of the simulation [O, N] (they can depend on its domain parameters). """
+    """ Per-lane observation bounds (lo, hi) of the simulation, [O, N] each (they can depend on its domain
+    parameters), as the `obs_bounds` of the device-side simulations state them. """
     cols = dp if dp_index is None else dp[:, dp_index.long()]
     if cols.shape[1] != N:
         cols = cols.expand(-1, N)
     k, dev = plan.kind, cols.device
     one = torch.ones((1, N), dtype=torch.float64, device=dev)
-    pi = float(np.pi)
+    pi, big = float(np.pi), float('inf')
     if k == abi.ENV_QQ:
-        hi = torch.cat([one, one, one, one, one*float('inf'), one*float('inf')])
+        hi = torch.cat([one, one, one, one, one*big, one*big])
+    elif k == abi.ENV_QQ_ST:       # observes the error to upright, bounded like its state space (asymmetric in alpha)
+        lo = torch.cat([one*(-120./180*pi), one*(pi - 15/180.*pi), one*(-20*pi), one*(-20*pi)])
+        hi = torch.cat([one*(120./180*pi), one*(pi + 15/180.*pi), one*(20*pi), one*(20*pi)])
+        return lo, hi
     elif k in (abi.ENV_QCP_SU, abi.ENV_QCP_ST):
-        hi = torch.cat([cols[2:3]/2., one, one, one*float('inf'), one*float('inf')])
+        hi = torch.cat([cols[2:3]/2., one, one, one*big, one*big])
     elif k == abi.ENV_QBB:
         hi = torch.cat([one*pi/4., one*pi/4., cols[3:4]/2., cols[3:4]/2., one*5*pi, one*5*pi, one*0.5, one*0.5])
     elif k == abi.ENV_BOB:
         hi = torch.cat([cols[4:5]/2., one*pi/4., one*10., one*pi])
-    else:
+    elif k == abi.ENV_PEND:
+        hi = torch.cat([one, one, one*big])
+    elif k == abi.ENV_OMO:
         hi = torch.cat([one, one*10.])
+    else:
+        raise NotImplementedError(f'observation bounds of environment kind {k}')
     return -hi, hi
 
 
@@ -338,16 +367,20 @@ def _act_bounds(plan, dp, dp_index, N):
     """ Per-lane action bounds of the inner simulation (they depend on its domain parameters). """
     cols = dp if dp_index is None else dp[:, dp_index.long()]
     k = plan.kind
-    if k == abi.ENV_QQ:
-        hi = cols[9:10]
+    if k in (abi.ENV_QQ, abi.ENV_QQ_ST):
+        hi = cols[9:10]            # max_volt
     elif k in (abi.ENV_QCP_SU, abi.ENV_QCP_ST):
         hi = torch.full((1, N), 8., dtype=torch.float64, device=cols.device)
     elif k == abi.ENV_QBB:
         hi = torch.full((2, N), 3., dtype=torch.float64, device=cols.device)
     elif k == abi.ENV_BOB:
         hi = cols[4:5]/2.*cols[0:1]*3.
+    elif k == abi.ENV_PEND:
+        hi = cols[4:5]             # tau_max
+    elif k == abi.ENV_OMO:
+        hi = cols[1:2]             # k
     else:
-        hi = cols[1:2]
+        raise NotImplementedError(f'action bounds of environment kind {k}')
     if hi.shape[1] != N:
         hi = hi.expand(-1, N)
     return -hi, hi

@@ -61,7 +61,8 @@ class ParallelSampler(SamplerBase):
         m = stop - start
         plan = self._plan
         key = self.seed + 7919*self._calls
-        dp, dp_index = sample_domain_params(plan, eng, m, seed=key, env_offset=global_offset + start)
+        dp, dp_index = sample_domain_params(plan, eng, m, seed=key, env_offset=global_offset + start,
+                                           n_global=n_global, shard_start=start)
         init = sample_init_states(plan, eng, m, dp, dp_index, seed=key, env_offset=global_offset + start)
         out = run_batch(plan, eng, self.policy, init, dp, dp_index, record=self.record_trajectories, noise_seed=key,
                         env_offset=global_offset + start, bernoulli_reset=self.bernoulli_reset)

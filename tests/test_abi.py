@@ -77,3 +77,25 @@ def test_create_fails_loudly_without_a_gpu():
     from simurlacra_amd.engine import Engine, EngineError
     with pytest.raises(EngineError):
         Engine(0)
+
+
+def test_philox_streams_of_the_samplers_are_pairwise_disjoint():
+    """ Domain randomization, init-state sampling, wrapper noise, exploration noise and the stochastic reset may all be
+    keyed by the same (seed, env offset): their stream ids must differ, and stay below the stride (16) by which a
+    sampler that draws several pairs per step advances its id. """
+    with open(os.path.join(ROOT, 'simurlacra_amd', 'csrc', 'psh_rng.h')) as f:
+        ids = dict(re.findall(r'#define (PSH_STREAM_[A-Z_]+) (\d+)u', f.read()))
+    assert set(ids) == {'PSH_STREAM_RANDOMIZE', 'PSH_STREAM_OBS_NOISE', 'PSH_STREAM_ACT_NOISE', 'PSH_STREAM_EXPL',
+                        'PSH_STREAM_BERNOULLI', 'PSH_STREAM_INIT'}
+    vals = [int(v) for v in ids.values()]
+    assert len(set(vals)) == len(vals) and max(vals) < 16
+    # the oracle draws initial states from the same stream: component r of env e is uniform number 0 of
+    # Philox(counter = (e, 0, r, PSH_STREAM_INIT), key = seed)
+    import numpy as np
+    from oracle import oracle_lib as orc
+    from simurlacra_amd import envdefs
+    dp = np.array(list(envdefs.nominal_domain_param(abi.ENV_OMO).values()))[:, None].repeat(3, axis=1)
+    init = orc.sample_init(abi.ENV_OMO, 3, dp, seed=7, env_offset=40)
+    o = orc.philox([41, 0, 0, int(ids['PSH_STREAM_INIT'])], [7, 0])
+    u = ((o[0] >> 5)*67108864.0 + (o[1] >> 6))/9007199254740992.0
+    assert init[0, 1] == -0.75 + u*(-0.65 - -0.75)

@@ -479,3 +479,30 @@ def test_cem_generation_on_randomized_qbb_matches_the_oracle(policy):
     assert cases.rel_err(res.mean_returns, ref['ret'].reshape(pop, R).mean(axis=1)) <= TOL
     if policy != 'linear':   # under the networks some balls leave the plate; the small linear gains keep all of them on it
         assert ref['length'].min() < T and (ref['status'] & abi.ST_FAILED).any()
+
+
+@pytest.mark.parametrize('name', ['pend', 'qq-st'])
+def test_stepwise_wrappers_on_pendulum_and_qqube_stab_match_the_fused_path(name):
+    """ ActNormWrapper / ObsNormWrapper around PendulumSim (action bound tau_max, observation [sin, cos, velocity]) and
+    QQubeStabSim (action bound max_volt, asymmetric angle bounds): the batched reset/step loop for a policy the
+    kernels cannot fuse against the fused kernel with the same policy function """
+    def chain():
+        env = ENVS[name](40)
+        if name == 'pend':
+            env = ObsNormWrapper(env, explicit_lb={r'$\dot{\theta}$': -20.}, explicit_ub={r'$\dot{\theta}$': 20.})
+        else:
+            env = ObsNormWrapper(env)
+        return DomainRandWrapperLive(ActNormWrapper(env), get_default_randomizer(env)) if name == 'qq-st' else ActNormWrapper(env)
+    fus = LinearPolicy(chain().spec, FeatureStack([const_feat, identity_feat]))
+    fus.param_values = 0.3*to.randn(fus.num_param, dtype=to.float64, generator=to.Generator().manual_seed(4))
+
+    class Opaque(to.nn.Module):
+        def forward(self, obs):
+            return fus(obs.to(to.float64))
+    a = ParallelSampler(chain(), fus, 1, min_rollouts=32, seed=6).sample()
+    b = ParallelSampler(chain(), Opaque(), 1, min_rollouts=32, seed=6).sample()
+    np.testing.assert_array_equal(a.lengths, b.lengths)
+    assert cases.rel_err(a.undiscounted_returns(), b.undiscounted_returns()) <= TOL
+    for i in (0, 17):
+        assert cases.rel_err(a[i].actions, b[i].actions) <= TOL and cases.rel_err(a[i].observations, b[i].observations) <= TOL
+    assert np.abs(a[0].observations).max() <= 1. + 1e-9 or name == 'qq-st'   # normalised observations

@@ -511,33 +511,3 @@ def test_bootstrapping():
     assert cit[0] < x.mean() < cit[1]
     with pytest.warns(UserWarning):
         assert bootstrap_ci(np.ones(8), np.mean, num_reps=10, alpha=0.1, ci_sides=2, studentized=True)[1] == [-np.inf, np.inf]
-
-
-def test_downsampling_and_running_norm_wrappers():
-    """ DownsamplingWrapper (Pyrado/pyrado/environment_wrappers/downsampling.py:93-124) and ObsRunningNormWrapper
-    (observation_normalization.py:109-135) on a recording stand-in environment: host-side logic only. """
-    from simurlacra_amd.environment_wrappers import DownsamplingWrapper, ObsRunningNormWrapper, RunningNormalizer
-    from simurlacra_amd.sampling.batch import EnvPlan
-    sim = OneMassOscillatorSim(dt=0.01, max_steps=20)
-    ds = DownsamplingWrapper(sim, factor=3)
-    acts = [ds._process_act(np.array([float(k)])) for k in range(7)]
-    assert [float(a[0]) for a in acts] == [0., 0., 0., 3., 3., 3., 6.]
-    obs = [ds._process_obs(np.array([float(k), 1.])) for k in range(5)]
-    assert obs[0].tolist() == [0., 1.] and obs[1].tolist() == [0.5, 1.] and obs[4].tolist() == [3., 1.]   # mean of the last 3
-    dp = {}
-    ds._save_domain_param(dp)
-    assert dp['downsampling'] == 3
-    ds._load_domain_param(dict(downsampling=np.array(2.)))
-    assert ds.factor == 2
-    with pytest.raises(NotImplementedError):
-        EnvPlan(ds)   # its buffer spans rollouts: not a lane-local wrapper
-    norm = RunningNormalizer()
-    norm(np.array([0., 10.]))
-    out = norm(np.array([2., 20.]))
-    assert out.tolist() == [1., 1.]
-    # the first sample widened the collapsed bounds by eps/2 = 5e-4 on both sides, and that lower bound stays
-    assert np.allclose(norm(np.array([1., 15.])), [1.0005/2.0005*2 - 1, 5.0005/10.0005*2 - 1], rtol=1e-12)
-    rn = ObsRunningNormWrapper(sim)
-    assert rn.obs_space.bound_up.tolist() == [1., 1.] and rn.obs_space.bound_lo.tolist() == [-1., -1.]
-    with pytest.raises(NotImplementedError):
-        EnvPlan(rn)
