@@ -31,7 +31,7 @@ FLOP_PER_STEP = 9352          # algorithmic fp64 flop per env-step, QQube + FNN 
 FP64_PEAK_TFLOPS = 78.6       # MI355X dense FP64 (matrix = vector rate: half the 157.3 TF FP32 peak)
 # HBM bytes per launch of the rollout kernel cannot be measured from inside this script: they come from the rocprofv3
 # counter passes over this same command (tools/profile_bench.sh), whose summary is committed next to the kernel trace.
-TRAFFIC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_bench_summary.json')
+TRAFFIC_SUMMARIES = ['r02_bench_summary.json', 'r01_bench_summary.json']   # newest first, under profiles/
 DT, T = 1/500., 600
 
 
@@ -163,10 +163,15 @@ def main():
     steps_k = int(steps_k.item())
     achieved = FLOP_PER_STEP*steps_k/(k_ms*1e-3)/1e12
 
-    traffic = None
-    if os.path.exists(TRAFFIC_SUMMARY) and (n_sets, R) == (8, 262144):  # the summary holds for the default workload only
-        with open(TRAFFIC_SUMMARY) as f:
-            traffic = json.load(f).get('hbm_bytes_per_launch')
+    traffic = traffic_source = None
+    if (n_sets, R) == (8, 262144):  # the committed counter runs hold for the default workload only
+        for name in TRAFFIC_SUMMARIES:
+            path = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    traffic = json.load(f).get('hbm_bytes_per_launch')
+                traffic_source = f'profiles/{name} (rocprofv3 FETCH_SIZE/WRITE_SIZE passes over this command, not this run)'
+                break
 
     res = None
     if rank == 0:
@@ -180,7 +185,7 @@ def main():
                        'domain_param_sets_per_gpu': n_sets, 'rollouts_per_set': R, 'envs_per_gpu': N,
                        'env_steps_counted': 'executed before done', 'parallelism': f'env-sharded x{world}'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic,
+                         'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'k_rollout_fnn<QQ,64>', 'kernel_ms': k_ms, 'env_steps_per_launch': steps_k,
                          'flop_per_env_step': FLOP_PER_STEP},
         }
@@ -192,11 +197,28 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpu():
+    """ what the box reports about its host CPU: model string, logical CPUs of the whole machine, CPUs this process may
+    run on """
+    model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            model = next((line.split(':', 1)[1].strip() for line in f if line.startswith('model name')), None)
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = None
+    return dict(cpu_model=model, host_cpu_count=os.cpu_count(), cpus_allowed=allowed)
+
+
 def cpu_baseline(eng, sets, task_c, ps, params, target_s=12.0):
     """ The C oracle (scalar fp64 restatement of the reference, OpenMP over envs) on a bounded sample of the same
-    workload, timed on this box's host cores. """
+    workload, timed on this box's host cores with the OpenMP default (OMP_NUM_THREADS, the share of the machine a
+    one-GPU job gets), next to the reference-style leg (one Python environment per rollout through a process pool). """
     from oracle import oracle_lib as orc
-    threads = min(orc.lib().orc_num_threads(), 16)
+    threads = orc.lib().orc_num_threads()
     distrs, nominal = sets[0]
 
     def sample(n, seed):
@@ -215,9 +237,26 @@ def cpu_baseline(eng, sets, task_c, ps, params, target_s=12.0):
     t0 = time.perf_counter()
     o = orc.rollout(abi.ENV_QQ, DT, T, task_c, ps, p, init, dp, n_threads=threads)
     el = time.perf_counter() - t0
-    return {'value': float(o['length'].sum()/el), 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} envs of the same workload (set 0), {int(o["length"].sum())} env-steps in {el:.1f} s, '
-                      f'C restatement of the reference (oracle/pysim_oracle.c, -O2, OpenMP over envs)'}
+    res = {'value': float(o['length'].sum()/el), 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{n} envs of the same workload (set 0), {int(o["length"].sum())} env-steps in {el:.1f} s, '
+                     f'C restatement of the reference (oracle/pysim_oracle.c, -O2, OpenMP over envs, {threads} threads)'}
+    res.update(host_cpu())
+    try:
+        res['reference_style'] = reference_style_baseline(min(threads, 16))
+    except Exception as exc:  # the pool is a courtesy leg: its failure must not lose the GPU numbers
+        res['reference_style'] = {'error': repr(exc)}
+    return res
+
+
+def reference_style_baseline(workers, target_s=5.0):
+    """ BASELINE configs[0] in the reference's cost model (Pyrado/pyrado/sampling/parallel_sampler.py:104-123,
+    sampler_pool.py:286-418): rollouts spread over a pool of worker processes, each stepping a NumPy environment in the
+    interpreter.  Runs as a child process of its own (tools/np_pool_baseline.py): its pool forks, which a process
+    holding a GPU context must not do. """
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'np_pool_baseline.py'), str(workers), '--seconds',
+                          str(target_s), '--json'], capture_output=True, text=True, timeout=120, check=True).stdout
+    return json.loads(out.strip().splitlines()[-1])
 
 
 if __name__ == '__main__':

@@ -35,11 +35,32 @@ def one_rollout(seed):
 
 
 if __name__ == '__main__':
-    workers = int(sys.argv[1]) if len(sys.argv) > 1 else min(16, os.cpu_count())
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20*workers
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument('workers', nargs='?', type=int, default=min(16, os.cpu_count()))
+    ap.add_argument('rollouts', nargs='?', type=int, default=None, help='rollouts to time (default: from --seconds)')
+    ap.add_argument('--seconds', type=float, default=5.0, help='target duration when no rollout count is given')
+    ap.add_argument('--json', action='store_true')
+    args = ap.parse_args()
+    workers = args.workers
     with mp.Pool(workers) as pool:
         pool.map(one_rollout, range(workers))          # start the workers before the clock
         t0 = time.perf_counter()
-        steps = sum(pool.map(one_rollout, range(100, 100 + n), chunksize=1))
+        steps = sum(pool.map(one_rollout, range(100, 100 + workers), chunksize=1))
+        n = workers
+        if args.rollouts is None:
+            more = workers*int(max(1, min(40, args.seconds/max(time.perf_counter() - t0, 1e-3) - 1)))
+        else:
+            more = max(0, args.rollouts - workers)
+        if more:
+            steps += sum(pool.map(one_rollout, range(1000, 1000 + more), chunksize=1))
+            n += more
         el = time.perf_counter() - t0
-    print(f'{steps/el:.1f} env-steps/s with {workers} worker processes ({n} rollouts, {steps} steps, {el:.1f} s)')
+    if args.json:
+        print(json.dumps({'value': steps/el, 'unit': 'env-steps/s', 'cores': workers, 'kind': 'port',
+                          'sample': f'{n} rollouts of QQubeSim (dt 1/500, T 600) + default randomizer + LinearPolicy(identity) '
+                                    f'(BASELINE configs[0]), {steps} env-steps in {el:.1f} s, NumPy restatement stepped in the '
+                                    f'interpreter by {workers} worker processes'}))
+    else:
+        print(f'{steps/el:.1f} env-steps/s with {workers} worker processes ({n} rollouts, {steps} steps, {el:.1f} s)')
