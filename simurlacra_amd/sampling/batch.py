@@ -482,3 +482,94 @@ class RolloutBatch(Sequence):
         done[-1] = True
         return StepSequence(observations=h['obs'][:L + 1, :, g], actions=h['act'][:L, :, g], rewards=h['rew'][:L, g],
                             env_infos=dict(t=np.arange(L)*self.dt), rollout_info=info, done=done, complete=True)
+
+
+class SummaryRollouts(Sequence):
+    """ Rollouts known only by their results (returns, lengths, domain parameters): what a rank holds of the rollouts
+    that ran on other GPUs.  Items are RolloutSummary objects built on access. """
+
+    def __init__(self, ret: np.ndarray, length: np.ndarray, dp_of=None, env_spec=None):
+        self._ret, self._length, self._dp_of, self._env_spec = np.asarray(ret), np.asarray(length), dp_of, env_spec
+
+    def __len__(self):
+        return int(self._ret.shape[0])
+
+    def undiscounted_returns(self) -> np.ndarray:
+        return self._ret
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return self._length
+
+    @property
+    def num_steps(self) -> int:
+        return int(self._length.sum())
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        info = dict(env_spec=self._env_spec, domain_param=None if self._dp_of is None else self._dp_of(i))
+        return RolloutSummary(self._ret[i], self._length[i], info)
+
+
+class GatheredBatch(Sequence):
+    """ A sampling call under torch.distributed as every rank sees it: ALL n_global rollouts, in global order.  Returns,
+    lengths, status words and (when each rollout drew its own) domain parameters were all-gathered; trajectories stay
+    on the GPU that produced them, so rollouts [start, stop) of this rank are full items of its RolloutBatch and the
+    others are RolloutSummary objects.  len(), undiscounted_returns(), lengths, num_steps and slicing therefore agree on
+    every rank, as the reference's algorithms expect of the list sample() returns. """
+
+    def __init__(self, local: RolloutBatch, gathered: dict, start: int, n_global: int):
+        self.local, self.start, self.stop, self._n = local, start, start + len(local), n_global
+        self.gathered = gathered
+        self._host = {k: v.detach().cpu().numpy() for k, v in gathered.items()}
+
+    def __len__(self):
+        return self._n
+
+    @property
+    def device_results(self) -> dict:
+        return self.local.device_results
+
+    def undiscounted_returns(self) -> np.ndarray:
+        return self._host['ret']
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return self._host['length']
+
+    @property
+    def num_steps(self) -> int:
+        return int(self._host['length'].sum())
+
+    def domain_param(self, i: int) -> dict:
+        if self.start <= i < self.stop:
+            return self.local.domain_param(i - self.start)
+        if 'domain_param' not in self._host:
+            return None
+        return self.local.plan.dp_dicts(self._host['domain_param'], [i], self.local._extra)[0]
+
+    def check(self):
+        st = self._host['status']
+        bad = np.flatnonzero(st & (abi.ST_BAD_INDEX | abi.ST_NAN))
+        if bad.size:
+            raise ValueErr(msg=f'At least one value is NaN or an index is outside its table! (rollout {int(bad[0])} of '
+                               f'the batch, {bad.size} in total)')
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if self.start <= i < self.stop:
+            return self.local[i - self.start]
+        info = dict(env_spec=self.local._env_spec, domain_param=self.domain_param(i))
+        return RolloutSummary(self._host['ret'][i], self._host['length'][i], info)

@@ -13,7 +13,7 @@ import torch
 from .. import inf
 from ..utils.exceptions import ValueErr
 from . import distributed as D
-from .batch import EnvPlan, RolloutBatch, run_batch, sample_domain_params, sample_init_states
+from .batch import EnvPlan, GatheredBatch, RolloutBatch, run_batch, sample_domain_params, sample_init_states
 
 
 class SamplerBase:
@@ -77,17 +77,17 @@ class ParallelSampler(SamplerBase):
         if self.min_steps is None:
             batch = self._sample_n(eng, self.min_rollouts, 0, self.min_rollouts)
             self._calls += 1
-            batch.check()
-            return self._gathered(batch, self.min_rollouts)
+            batch = self._gathered(batch, self.min_rollouts)
+            batch.check()          # after the gather: every rank raises for a NaN on any of them
+            return batch
         # at least min_steps steps (and min_rollouts rollouts): top up until both are met, keep everything
         n = max(self.min_rollouts or 0, math.ceil(self.min_steps/int(T)))
         parts, steps, done_rollouts = [], 0, 0
         while steps < self.min_steps or done_rollouts < (self.min_rollouts or 0):
-            b = self._sample_n(eng, n, done_rollouts, n)
+            b = self._gathered(self._sample_n(eng, n, done_rollouts, n), n)
             b.check()
-            b = self._gathered(b, n)
             parts.append(b)
-            steps += int(b.gathered['length'].sum().item()) if hasattr(b, 'gathered') else b.num_steps
+            steps += b.num_steps
             done_rollouts += n
             self._calls += 1
             remaining = self.min_steps - steps
@@ -97,7 +97,8 @@ class ParallelSampler(SamplerBase):
         return parts[0] if len(parts) == 1 else _ConcatBatches(parts)
 
     def _gathered(self, batch: RolloutBatch, n_global: int):
-        """ Attach the all-gathered per-rollout results (returns, lengths, status, domain parameters). """
+        """ Under torch.distributed: all-gather the per-rollout results (returns, lengths, status, domain parameters)
+        and return the view of all n_global rollouts that is the same on every rank. """
         rank, ws = D.world()
         if ws == 1:
             return batch
@@ -106,8 +107,7 @@ class ParallelSampler(SamplerBase):
                  status=D.all_gather_rows(out['status'], n_global))
         if batch._dp_index is None:
             g['domain_param'] = D.all_gather_rows(batch._dp.t().contiguous(), n_global).t()
-        batch.gathered = g
-        return batch
+        return GatheredBatch(batch, g, D.shard_range(n_global, rank, ws)[0], n_global)
 
 
 ParallelRolloutSampler = ParallelSampler

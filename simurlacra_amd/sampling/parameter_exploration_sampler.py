@@ -14,7 +14,9 @@ import torch as to
 from ..environment_wrappers.domain_randomization import DomainRandWrapper, remove_all_dr_wrappers
 from ..environment_wrappers.utils import typed_env
 from . import distributed as D
-from .batch import EnvPlan, RolloutBatch, run_batch, sample_domain_params, sample_init_states
+from .. import _abi as abi
+from ..utils.exceptions import ValueErr
+from .batch import EnvPlan, RolloutBatch, SummaryRollouts, run_batch, sample_domain_params, sample_init_states
 
 
 class ParameterSample(NamedTuple):
@@ -110,12 +112,29 @@ class ParameterExplorationSampler:
         out = run_batch(plan, eng, self.policy, init, dp, r_idx, record=self.record_trajectories, params=my_params,
                         policy_group=R if my > 1 else 0, noise_seed=key, env_offset=p0*R)
         batch = RolloutBatch(plan, out, dp, r_idx)
-        batch.check()
         means = eng.segment_mean(out['ret'], R) if lanes > 0 else to.empty(0, dtype=to.float64, device=dev)
         means = D.all_gather_rows(means, pop).cpu().numpy()
+        if ws == 1:
+            batch.check()
+            samples = [ParameterSample(params=param_sets[j], rollouts=batch.slice(j*R, R)) for j in range(pop)]
+            return ParameterSamplingResult(samples, means)
+        # every rank gets the returns, lengths and status words of ALL parameter sets ([pop, R] each; trajectories
+        # stay where they were produced), so num_rollouts, len(rollout) and slicing of the result agree on all ranks
+        ret = D.all_gather_rows(out['ret'].view(my, R), pop).cpu().numpy()
+        length = D.all_gather_rows(out['length'].view(my, R), pop).cpu().numpy()
+        status = D.all_gather_rows(out['status'].view(my, R), pop).cpu().numpy()
+        if (status & (abi.ST_NAN | abi.ST_BAD_INDEX)).any():
+            j, r = np.argwhere(status & (abi.ST_NAN | abi.ST_BAD_INDEX))[0]
+            raise ValueErr(msg=f'At least one value is NaN! (rollout {int(r)} of parameter set {int(j)})')
+        dp_host = dp.detach().cpu().numpy()          # the R shared columns, identical on every rank
+
+        def dp_of(r):
+            return plan.dp_dicts(dp_host, [r])[0]
         samples = []
         for j in range(pop):
-            local = p0 <= j < p1
-            ros = batch.slice((j - p0)*R, R) if local else []
+            if p0 <= j < p1:
+                ros = batch.slice((j - p0)*R, R)
+            else:
+                ros = SummaryRollouts(ret[j], length[j], dp_of, batch._env_spec)
             samples.append(ParameterSample(params=param_sets[j], rollouts=ros))
         return ParameterSamplingResult(samples, means)

@@ -63,3 +63,121 @@ def test_all_gather_rows_world_size_2(n_total):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res) and all(r[2][1] == 2 for r in res)
+
+
+# ------------------------------------------------------------------ the samplers under torch.distributed (gloo, CPU)
+class _StubEngine:
+    """ Stands in for the GPU engine in processes without one: every result is a function of the GLOBAL rollout index
+    (and of the policy parameters), so the test can tell whether each rank sees every rollout in its place. """
+    device = torch.device('cpu')
+
+    def f64(self, a, shape=None):
+        t = torch.as_tensor(np.asarray(a, dtype=np.float64) if not torch.is_tensor(a) else a, dtype=torch.float64).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+    def i32(self, a):
+        return None if a is None else torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a, dtype=torch.int32).contiguous()
+
+    def randomize(self, n_envs, distrs, nominal_rows, seed, env_offset=0):
+        out = torch.tensor(nominal_rows, dtype=torch.float64).reshape(-1, 1).repeat(1, n_envs)
+        out[0] = 9.81 + 1e-3*(env_offset + torch.arange(n_envs, dtype=torch.float64))   # g carries the global index
+        return out
+
+    def sample_init(self, env_kind, n_envs, domain_param, seed, env_offset=0, dp_index=None):
+        from simurlacra_amd import _abi as abi
+        return torch.zeros((abi.ENV_DIMS[env_kind][4], n_envs), dtype=torch.float64)
+
+    def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *, flags=1, dp_index=None,
+                policy_index=None, policy_group=0, record=False, wrap=None, bernoulli_reset=0., final_state=True, out=None):
+        from simurlacra_amd import _abi as abi
+        S, O, A, P, _ = abi.ENV_DIMS[env_kind]
+        n, T = init_state.shape[1], int(max_steps)
+        g = wrap.env_offset + torch.arange(n, dtype=torch.float64)
+        params = self.f64(params).reshape(-1, policy_spec.num_param)
+        ret = g.clone()
+        if policy_group > 0:
+            ret = params.sum(dim=1).repeat_interleave(policy_group) + 1e-3*(g % policy_group)
+        res = dict(ret=ret, length=(g.to(torch.int32) % T) + 1, status=torch.zeros(n, dtype=torch.int32),
+                   final_state=torch.zeros((S, n), dtype=torch.float64))
+        if record:
+            res.update(obs=torch.zeros((T + 1, O, n), dtype=torch.float64), act=torch.zeros((T, A, n), dtype=torch.float64),
+                       rew=torch.zeros((T, n), dtype=torch.float64))
+            res['rew'][0] = ret                               # the rewards of a trajectory add up to its return
+        return res
+
+    def segment_mean(self, ret, group_size):
+        return ret.reshape(-1, group_size).mean(dim=1)
+
+
+def _sampler_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import simurlacra_amd.engine as engine
+        stub = _StubEngine()
+        engine.get_engine = lambda device=None: stub
+        from simurlacra_amd.domain_randomization import get_default_randomizer
+        from simurlacra_amd.environment_wrappers import DomainRandWrapperLive
+        from simurlacra_amd.environments import QQubeSim
+        from simurlacra_amd.policies import FeatureStack, LinearPolicy, identity_feat
+        from simurlacra_amd.sampling import ParallelSampler, ParameterExplorationSampler
+        from simurlacra_amd.sampling.batch import RolloutSummary
+        T = 7
+        env = QQubeSim(dt=0.01, max_steps=T)
+        renv = DomainRandWrapperLive(env, get_default_randomizer(env))
+        pol = LinearPolicy(renv.spec, FeatureStack([identity_feat]))
+        # ParallelSampler: 11 rollouts over 2 ranks (6 + 5); every rank sees all 11 in global order
+        ros = ParallelSampler(renv, pol, 1, min_rollouts=11, seed=1).sample()
+        failed = []
+
+        def chk(idx, cond):
+            if not cond:
+                failed.append(idx)
+        chk(0, len(ros) == 11)
+        chk(1, np.array_equal(ros.undiscounted_returns(), np.arange(11.)))
+        chk(2, np.array_equal(ros.lengths, np.arange(11) % T + 1) and ros.num_steps == int((np.arange(11) % T + 1).sum()))
+        start, stop = D.shard_range(11, rank, world)
+        for i in range(11):
+            ro = ros[i]
+            chk(3, ro.undiscounted_return() == float(i) and len(ro) == i % T + 1)
+            chk(4, isinstance(ro, RolloutSummary) == (not start <= i < stop))          # trajectories stay local
+            chk(5, abs(ro.rollout_info['domain_param']['g'] - (9.81 + 1e-3*i)) < 1e-12)   # gathered domain parameters
+        chk(6, [r.undiscounted_return() for r in ros[3:8]] == [3., 4., 5., 6., 7.])
+        # min_steps: the top-up loop sees the global step count on every rank and stops on the same round
+        ms = ParallelSampler(renv, pol, 1, min_steps=40, seed=1).sample()
+        chk(7, ms.num_steps >= 40 and len(ms) == len(ms.undiscounted_returns()))
+        n_ms = len(ms)
+        # ParameterExplorationSampler: 5 parameter sets (3 + 2) x 3 rollouts
+        pop, R = 5, 3
+        sets = torch.arange(pop*pol.num_param, dtype=torch.float64).reshape(pop, pol.num_param)
+        res = ParameterExplorationSampler(renv, pol, 1, R, seed=2).sample(sets)
+        want = sets.sum(dim=1).numpy()[:, None] + 1e-3*np.arange(R)[None, :]
+        chk(8, len(res) == pop and res.num_rollouts == pop*R)
+        chk(9, np.allclose(res.mean_returns, want.mean(axis=1), rtol=1e-14))
+        for j in range(pop):
+            chk(10, len(res[j].rollouts) == R and res[j].num_rollouts == R)
+            chk(11, np.allclose([ro.undiscounted_return() for ro in res[j].rollouts], want[j], rtol=1e-14))
+            chk(12, abs(res[j].mean_undiscounted_return - want[j].mean()) < 1e-9)
+            chk(13, all(len(ro) >= 1 for ro in res[j].rollouts))
+        half = res[1:]                                        # PEPG-style slicing of the result
+        chk(14, len(half) == pop - 1 and np.allclose(half.mean_returns, want[1:].mean(axis=1)))
+        q.put((rank, failed, n_ms))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_samplers_return_the_same_rollout_lists_on_every_rank():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] == [] for r in res), [r[:2] for r in res]   # numbers of the failed checks per rank
+    assert res[0][2] == res[1][2]
