@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 108
+#define PSH_VERSION 109
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -412,6 +412,23 @@ int psh_qbb_ik(psh_ctx* ctx, int32_t n, const double* th /*[dev][n]*/, const dou
  * groups of group_size returns each. */
 int psh_segment_mean(psh_ctx* ctx, int32_t n_groups, int32_t group_size, const double* ret /*[dev]*/,
                      double* mean /*[dev][n_groups]*/, void* stream);
+
+/* Elite selection of the population-based algorithms: indices (and values) of the k largest of n values in descending
+ * order, i.e. to.argsort(rets_avg_ros, descending=True)[:num_is_samples] of CEM.update
+ * (Pyrado/pyrado/algorithms/cem.py:116-119), argmax of HC (Pyrado/pyrado/algorithms/hc.py:66-82) with k = 1.  Ties are
+ * ordered by index; a NaN ranks above every number (as torch sorts it).  Applied to the all-gathered per-policy means
+ * it keeps the returns on the device between psh_segment_mean and the parameter update. */
+int psh_topk(psh_ctx* ctx, int32_t n, int32_t k, const double* values /*[dev][n]*/, int32_t* idx_out /*[dev][k]*/,
+             double* val_out /*[dev][k] or NULL*/, void* stream);
+
+/* Bootstrap replications of the mean, the resampling loop of bootstrap_ci
+ * (Pyrado/pyrado/sampling/bootstrapping.py:47-61 with stat_fcn = np.mean, as BayRn and SPOTA call it,
+ * Pyrado/pyrado/algorithms/bayrn.py:300-304): replication r is the mean of n draws with replacement from data[0..n).
+ * Draw j of replication r is data[floor(u n)] with u the (j & 1)-th uniform of Philox4x32-10 at counter
+ * (r, 0, j >> 1, stream 6) under key `seed`; the reference draws from NumPy's global generator, so only the
+ * distribution of the replications can agree with it. */
+int psh_bootstrap_means(psh_ctx* ctx, int32_t n, int32_t num_reps, const double* data /*[dev][n]*/, uint64_t seed,
+                        double* stat_bs /*[dev][num_reps]*/, void* stream);
 
 /* Diagnostic, no counterpart in the reference: evaluates one of the device's fp64 elementary functions
  * (the ones the step loop uses in place of NumPy's np.exp / np.tanh / np.sin / np.cos / np.fmod) element-wise, so that

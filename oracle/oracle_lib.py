@@ -48,6 +48,8 @@ def lib():
         L.orc_policy_forward.argtypes = [C.POINTER(abi.PshPolicy), C.c_int, C.c_int, abi.c_double_p, abi.c_double_p]
         L.orc_philox.restype = None
         L.orc_philox.argtypes = [C.POINTER(C.c_uint32*4), C.POINTER(C.c_uint32*2), C.POINTER(C.c_uint32*4)]
+        L.orc_bootstrap_means.restype = None
+        L.orc_bootstrap_means.argtypes = [C.c_int, C.c_int, abi.c_double_p, C.c_uint64, abi.c_double_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -213,3 +215,11 @@ def philox(ctr, key):
     o = (C.c_uint32*4)()
     lib().orc_philox(C.byref(c), C.byref(k), C.byref(o))
     return [int(v) for v in o]
+
+
+def bootstrap_means(data, num_reps, seed):
+    data = _f64(data).reshape(-1)
+    out = np.zeros(int(num_reps))
+    lib().orc_bootstrap_means(data.size, int(num_reps), data.ctypes.data_as(abi.c_double_p), int(seed),
+                              out.ctypes.data_as(abi.c_double_p))
+    return out

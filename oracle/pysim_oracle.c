@@ -1033,3 +1033,22 @@ int orc_sample_init(const psh_init_desc* d) {
     }
     return 0;
 }
+
+/* Bootstrap replications of the mean (Pyrado/pyrado/sampling/bootstrapping.py:47-61 with stat_fcn = np.mean), with the
+ * product's draws: draw j of replication r = data[floor(u n)], u the (j & 1)-th uniform of Philox at counter
+ * (r, 0, j >> 1, 6).  Summed in draw order. */
+void orc_bootstrap_means(int n, int num_reps, const double* data, uint64_t seed, double* out) {
+    for (int r = 0; r < num_reps; ++r) {
+        double acc = 0.;
+        for (int p = 0; 2 * p < n; ++p) {
+            double u0, u1;
+            draw2(seed, (uint64_t)r, (uint32_t)p, 6u, &u0, &u1);
+            int j0 = (int)(u0 * n), j1 = (int)(u1 * n);
+            if (j0 >= n) j0 = n - 1;
+            if (j1 >= n) j1 = n - 1;
+            acc += data[j0];
+            if (2 * p + 1 < n) acc += data[j1];
+        }
+        out[r] = acc / n;
+    }
+}

@@ -35,6 +35,7 @@ __device__ __forceinline__ double psh_u01(uint32_t hi, uint32_t lo) {
 #define PSH_STREAM_EXPL 3u        // action-noise exploration, row = step
 #define PSH_STREAM_BERNOULLI 4u   // stochastic reset, row = step
 #define PSH_STREAM_INIT 5u        // initial states, row = component
+#define PSH_STREAM_BOOTSTRAP 6u   // bootstrap resampling, env = replication, row = draw pair
 
 // two uniforms for (seed, env, row, stream)
 __device__ __forceinline__ void psh_draw2(uint64_t seed, uint64_t env, uint32_t row, uint32_t stream, double& ua, double& ub) {

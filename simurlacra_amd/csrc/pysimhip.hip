@@ -265,6 +265,50 @@ __global__ __launch_bounds__(256) void k_segment_mean(int n_groups, int group_si
     if (lane == 0) mean[g] = acc / group_size;
 }
 
+// Descending rank of every value by counting the values ahead of it (greater, or equal with a smaller index; a NaN is
+// ahead of every number).  n threads x n comparisons with the values staged through LDS in tiles: for the population
+// sizes of CEM / NES (up to a few 10^4 per-policy means) that is microseconds, and the order is deterministic.
+__global__ __launch_bounds__(256) void k_topk(int n, int k, const double* __restrict__ v, int* __restrict__ idx_out, double* __restrict__ val_out) {
+    __shared__ double tile[256];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double mine = i < n ? v[i] : 0.;
+    const bool mine_nan = mine != mine;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        __syncthreads();
+        tile[threadIdx.x] = base + (int)threadIdx.x < n ? v[base + threadIdx.x] : 0.;
+        __syncthreads();
+        const int m = n - base < 256 ? n - base : 256;
+        for (int j = 0; j < m; ++j) {
+            const double o = tile[j];
+            const bool o_nan = o != o;
+            const bool ahead = o_nan ? (!mine_nan || base + j < i) : (!mine_nan && (o > mine || (o == mine && base + j < i)));
+            rank += ahead ? 1 : 0;
+        }
+    }
+    if (i < n && rank < k) {
+        idx_out[rank] = i;
+        if (val_out) val_out[rank] = mine;
+    }
+}
+
+// one wave per bootstrap replication: n draws with replacement, summed over the lanes
+__global__ __launch_bounds__(256) void k_bootstrap_means(int n, int num_reps, const double* __restrict__ data, uint64_t seed, double* __restrict__ out) {
+    const int rep = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (rep >= num_reps) return;
+    double acc = 0.;
+    for (int p = lane; 2 * p < n; p += 64) {
+        double u0, u1;
+        psh_draw2(seed, (uint64_t)rep, (uint32_t)p, PSH_STREAM_BOOTSTRAP, u0, u1);
+        int j0 = (int)(u0 * n), j1 = (int)(u1 * n);
+        j0 = j0 < n ? j0 : n - 1; j1 = j1 < n ? j1 : n - 1;
+        acc += data[j0];
+        if (2 * p + 1 < n) acc += data[j1];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[rep] = acc / n;
+}
+
 // element-wise evaluation of the device math functions (accuracy tests)
 __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* x, const double* m, double* y, const double* tanh_tab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,6 +614,24 @@ extern "C" int psh_segment_mean(psh_ctx* c, int32_t n_groups, int32_t group_size
     if (n_groups == 0) return PSH_OK;
     PSH_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_segment_mean, dim3((n_groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_groups, group_size, ret, mean);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_topk(psh_ctx* c, int32_t n, int32_t k, const double* values, int32_t* idx_out, double* val_out, void* stream) {
+    if (!c || n < 0 || k < 0 || k > n || (k > 0 && (!values || !idx_out))) { set_err(c, "invalid top-k arguments (0 <= k <= n, non-NULL pointers)"); return PSH_ERR_ARG; }
+    if (k == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_topk, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)n, (int)k, values, idx_out, val_out);
+    PSH_HIP(c, hipGetLastError());
+    return PSH_OK;
+}
+
+extern "C" int psh_bootstrap_means(psh_ctx* c, int32_t n, int32_t num_reps, const double* data, uint64_t seed, double* stat_bs, void* stream) {
+    if (!c || n < 1 || num_reps < 0 || !data || (num_reps > 0 && !stat_bs)) { set_err(c, "invalid bootstrap arguments (n >= 1, non-NULL pointers)"); return PSH_ERR_ARG; }
+    if (num_reps == 0) return PSH_OK;
+    PSH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_bootstrap_means, dim3((num_reps + 3) / 4), dim3(256), 0, (hipStream_t)stream, (int)n, (int)num_reps, data, seed, stat_bs);
     PSH_HIP(c, hipGetLastError());
     return PSH_OK;
 }

@@ -242,6 +242,23 @@ class Engine:
                     'psh_segment_mean')
         return mean
 
+    def topk(self, values, k: int):
+        """ Indices (int32 [k]) and values ([k]) of the k largest entries in descending order, on the device. """
+        values = self.f64(values).reshape(-1)
+        idx = torch.empty(k, dtype=torch.int32, device=self.device)
+        val = torch.empty(k, dtype=torch.float64, device=self.device)
+        self._check(self.lib.psh_topk(self._h, values.numel(), int(k), _ptr(values), _ptr(idx), _ptr(val), self._stream()),
+                    'psh_topk')
+        return idx, val
+
+    def bootstrap_means(self, data, num_reps: int, seed: int):
+        """ [num_reps] means of len(data) draws with replacement each, on the device. """
+        data = self.f64(data).reshape(-1)
+        out = torch.empty(int(num_reps), dtype=torch.float64, device=self.device)
+        self._check(self.lib.psh_bootstrap_means(self._h, data.numel(), int(num_reps), _ptr(data), int(seed), _ptr(out),
+                                                 self._stream()), 'psh_bootstrap_means')
+        return out
+
 
 _engines = {}
 

@@ -35,9 +35,10 @@ class ParameterSample(NamedTuple):
 
 
 class ParameterSamplingResult(Sequence):
-    def __init__(self, samples: List[ParameterSample], mean_returns: np.ndarray = None):
+    def __init__(self, samples: List[ParameterSample], mean_returns: np.ndarray = None, mean_returns_device=None):
         self._samples = samples
         self._mean_returns = mean_returns
+        self._means_dev = mean_returns_device     # the same means, still on the GPU (all parameter sets, every rank)
 
     def __getitem__(self, idx):
         res = self._samples[idx]
@@ -58,6 +59,22 @@ class ParameterSamplingResult(Sequence):
         if self._mean_returns is None:
             self._mean_returns = np.array([s.mean_undiscounted_return for s in self._samples])
         return self._mean_returns
+
+    def elites(self, num: int):
+        """ The `num` parameter sets with the highest mean return, best first: (indices, their mean returns, their
+        parameters [num, num_param]) as CEM.update selects its importance samples
+        (Pyrado/pyrado/algorithms/cem.py:116-120).  Ranked on the GPU when the means are still there. """
+        num = min(int(num), len(self))
+        if self._means_dev is not None:
+            from ..engine import get_engine
+            idx, val = get_engine().topk(self._means_dev, num)
+            idx, val = idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+        else:
+            means = np.asarray(self.mean_returns, dtype=np.float64)
+            key = np.where(np.isnan(means), np.inf, means)
+            idx = np.lexsort((np.arange(len(key)), -key))[:num]
+            val = means[idx]
+        return idx, val, self.parameters[to.as_tensor(idx)]
 
     @property
     def rollouts(self) -> list:
@@ -113,11 +130,12 @@ class ParameterExplorationSampler:
                         policy_group=R if my > 1 else 0, noise_seed=key, env_offset=p0*R)
         batch = RolloutBatch(plan, out, dp, r_idx)
         means = eng.segment_mean(out['ret'], R) if lanes > 0 else to.empty(0, dtype=to.float64, device=dev)
-        means = D.all_gather_rows(means, pop).cpu().numpy()
+        means_dev = D.all_gather_rows(means, pop)
+        means = means_dev.cpu().numpy()
         if ws == 1:
             batch.check()
             samples = [ParameterSample(params=param_sets[j], rollouts=batch.slice(j*R, R)) for j in range(pop)]
-            return ParameterSamplingResult(samples, means)
+            return ParameterSamplingResult(samples, means, means_dev)
         # every rank gets the returns, lengths and status words of ALL parameter sets ([pop, R] each; trajectories
         # stay where they were produced), so num_rollouts, len(rollout) and slicing of the result agree on all ranks
         ret = D.all_gather_rows(out['ret'].view(my, R), pop).cpu().numpy()
@@ -137,4 +155,4 @@ class ParameterExplorationSampler:
             else:
                 ros = SummaryRollouts(ret[j], length[j], dp_of, batch._env_spec)
             samples.append(ParameterSample(params=param_sets[j], rollouts=ros))
-        return ParameterSamplingResult(samples, means)
+        return ParameterSamplingResult(samples, means, means_dev)

@@ -86,7 +86,7 @@ def test_philox_streams_of_the_samplers_are_pairwise_disjoint():
     with open(os.path.join(ROOT, 'simurlacra_amd', 'csrc', 'psh_rng.h')) as f:
         ids = dict(re.findall(r'#define (PSH_STREAM_[A-Z_]+) (\d+)u', f.read()))
     assert set(ids) == {'PSH_STREAM_RANDOMIZE', 'PSH_STREAM_OBS_NOISE', 'PSH_STREAM_ACT_NOISE', 'PSH_STREAM_EXPL',
-                        'PSH_STREAM_BERNOULLI', 'PSH_STREAM_INIT'}
+                        'PSH_STREAM_BERNOULLI', 'PSH_STREAM_INIT', 'PSH_STREAM_BOOTSTRAP'}
     vals = [int(v) for v in ids.values()]
     assert len(set(vals)) == len(vals) and max(vals) < 16
     # the oracle draws initial states from the same stream: component r of env e is uniform number 0 of

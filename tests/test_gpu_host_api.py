@@ -506,3 +506,53 @@ def test_stepwise_wrappers_on_pendulum_and_qqube_stab_match_the_fused_path(name)
     for i in (0, 17):
         assert cases.rel_err(a[i].actions, b[i].actions) <= TOL and cases.rel_err(a[i].observations, b[i].observations) <= TOL
     assert np.abs(a[0].observations).max() <= 1. + 1e-9 or name == 'qq-st'   # normalised observations
+
+
+def test_device_topk_matches_argsort():
+    """ psh_topk against NumPy: descending order, ties by index, NaN first (Pyrado/pyrado/algorithms/cem.py:116-119) """
+    from simurlacra_amd.engine import get_engine
+    eng = get_engine(0)
+    rng = np.random.default_rng(0)
+    for n, k in ((1, 1), (7, 3), (256, 256), (4097, 100), (50000, 500)):
+        v = rng.standard_normal(n)
+        v[rng.integers(0, n, n//10)] = np.round(v[rng.integers(0, n, n//10)], 1)      # ties
+        idx, val = eng.topk(v, k)
+        order = np.lexsort((np.arange(n), -v))[:k]
+        np.testing.assert_array_equal(idx.cpu().numpy(), order)
+        np.testing.assert_array_equal(val.cpu().numpy(), v[order])
+    v = np.array([1., np.nan, 3., 3., -np.inf, np.inf])
+    np.testing.assert_array_equal(eng.topk(v, 6)[0].cpu().numpy(), [1, 5, 2, 3, 0, 4])
+    # through the sampler's result object: CEM's importance samples
+    env = ENVS['omo'](30)
+    pol = LinearPolicy(env.spec, FeatureStack([identity_feat]))
+    sets = to.randn((64, pol.num_param), dtype=to.float64, generator=to.Generator().manual_seed(0))
+    res = ParameterExplorationSampler(env, pol, 1, 4, seed=0).sample(sets)
+    idx, val, params = res.elites(10)
+    want = np.argsort(-res.mean_returns, kind='stable')[:10]
+    np.testing.assert_array_equal(idx, want)
+    np.testing.assert_array_equal(val, res.mean_returns[want])
+    assert to.equal(params, sets[to.as_tensor(want)])
+    assert np.array_equal(res[10:30].elites(5)[0], np.argsort(-res.mean_returns[10:30], kind='stable')[:5])   # host ranking of a slice
+
+
+def test_device_bootstrap_matches_the_oracle_draws_and_the_host_interval():
+    """ psh_bootstrap_means against the C oracle's replications (same Philox draws, 1e-12) and bootstrap_ci_device
+    against the host's bootstrap_ci on the same returns: same statistic, intervals that agree within the
+    resampling noise (Pyrado/pyrado/sampling/bootstrapping.py:7-140) """
+    from oracle import oracle_lib as orc
+    from simurlacra_amd.engine import get_engine
+    from simurlacra_amd.sampling import bootstrap_ci, bootstrap_ci_device
+    eng = get_engine(0)
+    rng = np.random.default_rng(3)
+    for n, reps in ((1, 5), (37, 64), (1000, 257)):
+        x = rng.standard_normal(n)*3 + 1
+        got = eng.bootstrap_means(x, reps, seed=11).cpu().numpy()
+        assert cases.rel_err(got, orc.bootstrap_means(x, reps, 11)) <= 1e-12
+    x = rng.standard_normal(400) + 0.5
+    for kw in (dict(ci_sides=2), dict(ci_sides=1), dict(ci_sides=2, studentized=True), dict(ci_sides=2, bias_correction=True)):
+        m_h, ci_h = bootstrap_ci(x, np.mean, num_reps=4000, alpha=0.05, seed=1, **kw)
+        m_d, ci_d = bootstrap_ci_device(to.as_tensor(x, device=eng.device), num_reps=4000, alpha=0.05, seed=1, **kw)
+        tol = 0.06*(ci_h[1] - x.mean())         # resampling noise of two independent sets of 4000 replications
+        assert abs(m_d - m_h) < 5e-3
+        assert ci_d[0] == ci_h[0] == -np.inf or abs(ci_d[0] - ci_h[0]) < tol
+        assert abs(ci_d[1] - ci_h[1]) < tol and ci_d[0] < x.mean() < ci_d[1]
