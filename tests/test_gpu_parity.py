@@ -539,3 +539,53 @@ def test_device_math_accuracy(eng):
         got = eng.eval_math(fn, nan_in).cpu().numpy()
         assert np.isnan(got[0]) and got[1] == 1. and got[2] == -1., fn
     assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
+
+
+@pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 300.)], ids=['omo', 'bob'])
+def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, min_gbs):
+    """ 2^21 environments with full trajectories (T = 500): OneMassOscillator runs every episode to the end (34 GB of
+    trajectory), BallOnBeam ends after 69 steps on average, so every lane is refilled seven times and the wave's lanes
+    sit at different steps of environments from different chunks.  A sample of environments is compared with the
+    oracle step by step; for ALL of them the recorded rewards must add up to the returned return and the rows past an
+    episode's end must be untouched; the writeback rate must stay within reach of what profiles/ records. """
+    import torch
+    n, T = 1 << 21, 500
+    S, O, A, P, I = abi.ENV_DIMS[kind]
+    nom = envdefs.nominal_domain_param(kind)
+    distrs = [dict(kind=abi.DISTR_NORMAL, row=r, a=v, b=abs(v)/5, clip_lo=1e-3*abs(v)) for r, v in enumerate(nom.values()) if v != 0]
+    dp = eng.randomize(n, distrs, list(nom.values()), seed=1)
+    init = eng.sample_init(kind, n, dp, seed=1)
+    ps, params = cases.linear_policy(kind, np.random.default_rng(0), feats=('identity',), scale=0.1)
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    dev = eng.device
+    marker = -12345.0
+    out = dict(ret=torch.empty(n, dtype=torch.float64, device=dev), length=torch.empty(n, dtype=torch.int32, device=dev),
+               status=torch.empty(n, dtype=torch.int32, device=dev),
+               obs=torch.full((T + 1, O, n), marker, dtype=torch.float64, device=dev),
+               act=torch.full((T, A, n), marker, dtype=torch.float64, device=dev),
+               rew=torch.full((T, n), marker, dtype=torch.float64, device=dev))
+    eng.rollout(kind, cases.DT[kind], T, task_c, ps, params, init, dp, final_state=False, out=out)
+    eng.rollout(kind, cases.DT[kind], T, task_c, ps, params, init, dp, final_state=False, out=out)
+    ms = eng.last_rollout_ms()
+    length = out['length'].long()
+    steps = int(length.sum().item())
+    # every environment: rows below its length written, rows above untouched, rewards add up to the return
+    k = torch.arange(T, device=dev).unsqueeze(1)
+    live = k < length.unsqueeze(0)
+    assert bool(((out['rew'] != marker) == live).all())
+    assert bool(((out['obs'][:, 0, :] != marker) == (torch.arange(T + 1, device=dev).unsqueeze(1) <= length.unsqueeze(0))).all())
+    total = torch.where(live, out['rew'], torch.zeros((), dtype=torch.float64, device=dev)).sum(dim=0)
+    assert float(((total - out['ret']).abs()/out['ret'].abs().clamp(min=1.)).max()) <= 1e-9
+    # a sample of environments against the oracle, step by step
+    idx = torch.cat([torch.arange(0, 64), torch.arange(n - 64, n), torch.randint(0, n, (384,), generator=torch.Generator().manual_seed(0))]).to(dev)
+    ref = orc.rollout(kind, cases.DT[kind], T, task_c, ps, params, init[:, idx].cpu().numpy(), dp[:, idx].cpu().numpy(), record=True)
+    np.testing.assert_array_equal(out['length'][idx].cpu().numpy(), ref['length'])
+    np.testing.assert_array_equal(out['status'][idx].cpu().numpy(), ref['status'])
+    for key in ('obs', 'act', 'rew'):
+        got = out[key][..., idx].cpu().numpy()
+        got[got == marker] = np.nan
+        assert cases.rel_err(got, ref[key]) <= TOL, key
+    assert cases.rel_err(out['ret'][idx].cpu().numpy(), ref['ret']) <= TOL
+    gbs = (steps*(O + A + 1) + n*O)*8/ms/1e6
+    print(f'{cases.KIND_NAMES[kind]}: {steps/n:.1f} steps per episode, {ms:.2f} ms, {gbs:.0f} GB/s of trajectory bytes')
+    assert gbs >= min_gbs
