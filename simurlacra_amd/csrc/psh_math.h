@@ -100,6 +100,17 @@ PSH_MATH unsigned psh_tanh8_index(double x, double* d, unsigned* hi_abs) {
     *d = a - (jm - 26388279066624.0);
     return (unsigned)__double2loint(jm);       // <= 5120 by the clamp
 }
+// The same split for an argument KNOWN to lie within [-20, 20] (a hidden layer behind a tanh layer whose weights bound
+// its pre-activations): no clamp of |x| and no NaN bookkeeping, five 32-bit instructions less per element.  A NaN
+// needs no care here: it makes d a NaN, which the finish step carries into the result, and the index is limited to
+// the table, so whatever its low word holds, a table entry is read.
+PSH_MATH unsigned psh_tanh8_index_bounded(double x, double* d) {
+    const double a = fabs(x);
+    const double jm = a + 26388279066624.0;    // 1.5 * 2^44
+    *d = a - (jm - 26388279066624.0);
+    const unsigned j = (unsigned)__double2loint(jm);
+    return j < (unsigned)(PSH_TANH8_N - 1) ? j : (unsigned)(PSH_TANH8_N - 1);
+}
 PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
     const double z = d * d;
     const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;   // 2/15, -1/3; d^7 is below 2^-58

@@ -43,6 +43,7 @@ struct RolloutArgs {
 static_assert(sizeof(psh_task) % 8 == 0 && sizeof(psh_wrappers) % 8 == 0, "staged as doubles");
 static_assert(offsetof(RolloutArgs, wrap) == offsetof(RolloutArgs, task) + sizeof(psh_task), "staged as one block");
 constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
+constexpr double FNN_BOUND_LIMIT = 19.9;   // k_fnn_bounds: the tanh table ends at 20; the margin covers the rounding of the sums
 constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
 
 // The LDS copy is addressed through a base the compiler has to keep in ONE vector register (it cannot see through the
@@ -551,9 +552,22 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // layer, so a NaN in any of them has to end up in the action.  The table tanh loses NaNs (its clamp works on
 // the high word), so the largest |y| high word of the layer is tracked (one 32-bit max per element) and a NaN is put
 // back into y[0] once per layer.
-template <int N, bool FINE> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
+// BOUNDED: every |y| is known to stay below 20 (see FNN_BOUND_LIMIT): the cheaper index step without clamp.
+template <int N, bool FINE, bool BOUNDED = false> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
         unsigned hi_max = 0;
+        if (FINE && BOUNDED) {
+            constexpr int CH = N < 8 ? N : 8;
+#pragma unroll
+            for (int m0 = 0; m0 < N; m0 += CH) {
+                double d[CH], T[CH];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) T[m] = tanh_tab[psh_tanh8_index_bounded(y[m0 + m], &d[m])];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
+            }
+            return;
+        }
         if (FINE) {
             // all table loads first, then the arithmetic: the LDS latency is paid once per layer, not per element
             constexpr int CH = N < 8 ? N : 8;  // chunked: d and T of a whole layer would not fit the register file
@@ -756,7 +770,13 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
                 __builtin_amdgcn_s_setprio(PRIO_ACT);
-                nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
+                // behind a tanh layer the inputs lie in [-1, 1]: if the weights of this layer keep every pre-activation
+                // below the table's end (row sums of |W| plus |b|, computed by k_fnn_bounds), the clamp and the NaN
+                // bookkeeping of the activation are not needed
+                if (TANH && FINE && wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT)
+                    nl_apply_all<KS, FINE, true>((int)PSH_NL_TANH, y, tanh_tab);
+                else
+                    nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
@@ -783,6 +803,42 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
             }
         }
         if (L.live) L.post_policy(a, task, wrap, act);
+    }
+}
+
+// Largest pre-activation a hidden layer behind a bounded layer can produce: max over its units of sum_i |W[u][i]| + |b[u]|
+// (inputs in [-1, 1]).  Written behind the packed image, one double per layer (entry 0, the input layer, is infinite:
+// observations are not bounded).  A NaN or infinite weight yields a NaN or infinite bound, which fails the kernel's
+// comparison and keeps the clamping activation.  One wave per policy.
+static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restrict__ params, double* __restrict__ out, int total, int O,
+                                                   int A, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
+    params += (long)blockIdx.x * num_param;
+    out += (long)blockIdx.x * total + (total - 4);
+    const int hs[4] = {h0, h1, h2, h3};
+    const int u = threadIdx.x;
+    int poff = 0, last = O;
+    for (int l = 0; l < 4; ++l) {
+        double bound = 0.;
+        if (l < n_hidden) {
+            const int h = hs[l];
+            if (u < h) {
+                for (int i = 0; i < last; ++i) bound += fabs(params[poff + u * last + i]);
+                bound += fabs(params[poff + h * last + u]);
+            }
+            bool bad = bound != bound;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double other = __shfl_xor(bound, o);
+                bad = bad || (other != other);
+                bound = other > bound ? other : bound;
+            }
+            bad = __any(bad);
+            if (bad || l == 0) bound = __builtin_inf();
+            poff += h * last + h;
+            last = h;
+        } else {
+            bound = __builtin_inf();
+        }
+        if (u == 0) out[l] = bound;
     }
 }
 
@@ -962,7 +1018,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     }
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
     const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = E::O / 4, REM = E::O % 4;
-    const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2;
+    // the image: weight fragments, biases, output layer (2 doubles of bias), 4 doubles of per-layer bounds
+    const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2 + 4;
     double* wfrag = nullptr;
     {
         const int rc = scratch_doubles(c, PSH_SCR_WFRAG, (size_t)total * (per_env ? p.n_policies : 1), &wfrag);
@@ -971,6 +1028,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     hipLaunchKernelGGL(k_pack_fnn<KIND>, dim3((total + 255) / 256, per_env ? p.n_policies : 1), dim3(256), 0, st, p.params,
                        wfrag, total, Oe, (int)E::A, HP, K0, REM, p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3],
                        p.num_param);
+    PSH_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_fnn_bounds, dim3(per_env ? p.n_policies : 1), dim3(64), 0, st, p.params, wfrag, total, Oe, (int)E::A,
+                       p.n_hidden, p.hidden[0], p.hidden[1], p.hidden[2], p.hidden[3], p.num_param);
     PSH_HIP(c, hipGetLastError());
     a.wfrag = wfrag;
     a.lds_doubles = total;
