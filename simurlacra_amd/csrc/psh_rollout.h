@@ -28,7 +28,8 @@ struct RolloutArgs {
     double* delay_q;       // ACT_DELAY: ring buffers [PSH_MAX_DELAY][A][n_lanes], one column per resident lane
     long n_lanes;
     int num_feat;          // LINEAR: total feature count F
-    int lds_doubles;       // FNN: doubles of the packed weight image
+    int lds_doubles;       // FNN: doubles of the packed weight image as a workgroup holds it in LDS
+    int img_doubles;       // FNN: doubles of one packed weight image in global memory (>= lds_doubles)
     const double* wfrag;   // FNN: packed weight image (device)
     double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
     unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
@@ -36,6 +37,7 @@ struct RolloutArgs {
     const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
     int tanh_n;              // its length (fine or coarse table)
     int pop_tiles;           // FNN population mode: MFMA tiles (16 lanes each) per policy task: 1, 2 or 4
+    int pop_groups;          // FNN population mode: groups of pop_tiles tiles a wave uses (the lanes beyond stay empty)
 };
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
@@ -188,7 +190,7 @@ template <int KIND, bool WRAP> struct Lane {
         const unsigned long long busy = __ballot(i >= 0);
         const unsigned long long group = (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)) << first;
         bool got = false;
-        if ((busy & group) == 0 && !exhausted) {  // the same for all lanes of a group
+        if ((busy & group) == 0 && !exhausted && first < GL * a.pop_groups) {  // the same for all lanes of a group
             const int R = a.pol.policy_group, chunks = (R + GL - 1) / GL;
             unsigned int q = 0;
             if (lane == first) q = atomicAdd(a.queue, 1u);
@@ -618,9 +620,19 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // TANH: every hidden layer uses tanh, known at compile time.  With the nonlinearity chosen at run time the arms of
 // the switch meet again behind each layer and the register allocator moves all 16 activations of a tile into a common
 // place on every arm (32 v_mov_b64 per tile and layer, 3 % of the step); the usual all-tanh network does not pay that.
-template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH>
-__global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const RolloutArgs a) {
+//
+// WREG (population mode, two hidden layers of up to 64 units): the 64 x 64 weights between the hidden layers, 64 MFMA
+// fragments = 128 registers per lane, stay in the REGISTERS of the wave that runs the policy (the A operand of an MFMA
+// is a register anyway) instead of LDS.  Four images of 39 KB do not fit into a CU's LDS next to a tanh table, so the
+// LDS version keeps three waves per CU, one SIMD idle; without that block an image is 6 KB, one wave per SIMD runs
+// its policies (256 threads per workgroup leave a wave all 512 registers).  WREG = 1: the whole wave runs one policy
+// (more than 32 rollouts per policy); WREG = 2: tiles 0 and 1 of the wave run one policy each, two register sets, the
+// other 32 lanes stay empty -- eight policies resident per CU, and the environment step of a wave serves two of them.
+constexpr int NSET_OF(int wreg) { return wreg == 2 ? 2 : 1; }
+template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0>
+__global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
+    static_assert(!WREG || (POP && TANH && FINE && HP == 64), "WREG is the population kernel of the 64-wide tanh networks");
     // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
     // vector ALU (16 FMAs each per tile) instead of through a k-step that is half zeros (QQube's 6 inputs: 4 + 2)
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = E::O / 4, REM = E::O % 4;
@@ -638,7 +650,7 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
     // latency per layer: 100 us per step against 4)
     const int n_waves = (int)(blockDim.x >> 6);
     const int pop_shift = a.pop_tiles >> 1;     // log2 of 1, 2, 4
-    const int imgs = POP ? 4 >> pop_shift : 1;  // images per wave
+    const int imgs = WREG ? NSET_OF(WREG) : (POP ? 4 >> pop_shift : 1);  // images per wave
     const int w_doubles = POP ? n_waves * imgs * a.lds_doubles : a.lds_doubles;
     double* const w_lds = lds + (POP ? wave * imgs * a.lds_doubles : 0);
     double* const stage = lds + w_doubles + wave * (OP * 64);
@@ -660,6 +672,15 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
 
     const int n_hidden = a.pol.n_hidden;
     int pol = 0;  // POP: policy of this lane's group of tiles
+    // WREG: fragment (t, s) of the hidden-to-hidden weights of this wave's policy / of the policies of its tiles 0 and 1
+    constexpr int NSET = WREG == 2 ? 2 : 1;
+    double wreg[NSET][WREG ? HT * KS : 1];
+    if constexpr (WREG != 0) {
+#pragma unroll
+        for (int g = 0; g < NSET; ++g)
+#pragma unroll
+            for (int f = 0; f < HT * KS; ++f) wreg[g][f] = 0.;
+    }
     for (;;) {
         if constexpr (POP) {
             unsigned long long fresh;
@@ -668,9 +689,23 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                 while (fresh) {
                     const int first = __ffsll((long long)fresh) - 1;
                     fresh &= fresh - 1;
-                    const double* src = a.wfrag + (long)__shfl(pol, first) * a.lds_doubles;
+                    const double* src = a.wfrag + (long)__shfl(pol, first) * a.img_doubles;
                     double* dst = w_lds + (first >> (4 + pop_shift)) * a.lds_doubles;
-                    for (int j = lane; j < a.lds_doubles; j += 64) dst[j] = src[j];
+                    if constexpr (WREG != 0) {
+                        // the block of hidden-layer fragments goes to registers, what lies before and behind it to LDS
+                        constexpr int OFF1 = HT * K0 * 64 + REM * HP + HP, BLOCK = HT * KS * 64;
+                        for (int j = lane; j < OFF1; j += 64) dst[j] = src[j];
+                        for (int j = OFF1 + lane; j < a.lds_doubles; j += 64) dst[j] = src[j + BLOCK];
+                        if (NSET == 1 || first < 16) {
+#pragma unroll
+                            for (int f = 0; f < HT * KS; ++f) wreg[0][f] = src[OFF1 + f * 64 + lane];
+                        } else {
+#pragma unroll
+                            for (int f = 0; f < HT * KS; ++f) wreg[NSET - 1][f] = src[OFF1 + f * 64 + lane];
+                        }
+                    } else {
+                        for (int j = lane; j < a.lds_doubles; j += 64) dst[j] = src[j];
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -715,10 +750,11 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
 
         const unsigned long long live_mask = __ballot(L.live);
         __builtin_amdgcn_s_setprio(PRIO_ACT);
-        for (int tile = 0; tile < 4; ++tile) {
+        // one MFMA tile: the policy forward of 16 environments; `wr` holds the register-resident fragments of the tile's policy
+        auto run_tile = [&](const int tile, const double* wr) {
             // nobody in this tile needs an action: skip it (the drain at the end of a launch, when few long episodes
             // are left, then costs a quarter per step; population tasks with fewer than 64 rollouts)
-            if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) continue;
+            if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) return;
             const double* const wimg = POP ? w_lds + (tile >> pop_shift) * a.lds_doubles : w_lds;  // of this tile's policy
             double y[KS];
             // layer 0
@@ -751,7 +787,34 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
             }
             // further hidden layers
             int off = HT * K0 * 64 + REM * HP + HP;
-            for (int l = 1; l < n_hidden; ++l) {
+            if constexpr (WREG) {
+                // the second hidden layer from registers; the four output tiles advance together, so that consecutive
+                // MFMAs do not depend on each other (this wave has its SIMD to itself)
+                double x[KS];
+#pragma unroll
+                for (int m = 0; m < KS; ++m) x[m] = y[m];
+                const double* bl = wimg + off;
+                v4d acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] = bl[16 * t + 4 * r + q];
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[t * KS + s], x[s], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[t][r];
+                if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT)
+                    nl_apply_all<KS, FINE, true>((int)PSH_NL_TANH, y, tanh_tab);
+                else
+                    nl_apply_all<KS, FINE>((int)PSH_NL_TANH, y, tanh_tab);
+                off += HP;
+            }
+            for (int l = 1; !WREG && l < n_hidden; ++l) {
                 double x[KS];
 #pragma unroll
                 for (int m = 0; m < KS; ++m) x[m] = y[m];
@@ -791,6 +854,12 @@ __global__ __launch_bounds__((WRAP || POP) ? 512 : 768) void k_rollout_fnn(const
                 p += wo[E::A * HP + r];
                 if (q == tile) act[r] = p;
             }
+        };
+        if constexpr (WREG == 2) {   // two tiles, each with the register set of its own policy
+            run_tile(0, wreg[0]);
+            run_tile(1, wreg[1]);
+        } else {
+            for (int tile = 0; tile < 4; ++tile) run_tile(tile, wreg[0]);
         }
         __builtin_amdgcn_s_setprio(PRIO_ENV);
         // output nonlinearity, once per lane on its own action.  A branch the compiler must keep: without side
@@ -1034,6 +1103,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     PSH_HIP(c, hipGetLastError());
     a.wfrag = wfrag;
     a.lds_doubles = total;
+    a.img_doubles = total;
     // 8 waves per workgroup (2 per SIMD) or 12 (3 per SIMD, which the 168 registers of the bare kernels allow).  The third
     // wave hides more latency (+2..9 % throughput while the queue lasts), but every wave then steps 1.5 times slower,
     // and so does the drain at the end of a launch: taken when the queue fills the larger grid at least twice
@@ -1042,6 +1112,29 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // (and only if the four extra staging areas do not push the fine tanh table out of LDS)
     const bool fits12 = ((size_t)total + 12 * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
     const int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
+    if (per_env && HP == 64 && p.n_hidden == 2 && all_tanh) {
+        // population of two-hidden-layer tanh networks wider than 32: hidden-to-hidden weights in registers, one wave
+        // per SIMD (see WREG at the kernel).  Up to 32 rollouts per policy: two policies per wave, 16 rollouts per task;
+        // more: the whole wave on one policy, 64 rollouts per task.
+        const int block_l1 = HT * KS * 64;
+        const bool two = p.policy_group <= 32;
+        const int sets = two ? 2 : 1, task_lanes = two ? 16 : 64;
+        a.lds_doubles = total - block_l1;
+        a.pop_tiles = two ? 1 : 4;
+        a.pop_groups = two ? 2 : 1;
+        a.tanh_tab = c->tanh_tab;
+        a.tanh_n = PSH_TANH8_N;
+        const size_t lds_w = (4 * ((size_t)sets * a.lds_doubles + OP * 64) + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
+        if (lds_w <= c->lds_per_block) {
+            const long tasks = (long)p.n_policies * ((p.policy_group + task_lanes - 1) / task_lanes);
+            const long lanes = (tasks + sets - 1) / sets * 64;   // a wave takes `sets` tasks at a time
+#define PSH_LAUNCH_WREG(WRAP_, SETS_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
+            if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2) : PSH_LAUNCH_WREG(false, 2);
+            return wrapped ? PSH_LAUNCH_WREG(true, 1) : PSH_LAUNCH_WREG(false, 1);
+#undef PSH_LAUNCH_WREG
+        }
+        a.lds_doubles = total;
+    }
     if (per_env) {
         // population: the tiles of a wave in groups of G, one policy per group, the weight images of a wave's groups in
         // LDS next to its staging area.  G = 1, 2, 4 from the rollouts per policy (a group holds up to 16 G of them),
@@ -1070,6 +1163,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         fine = fine || waves_bytes + fixed_fine <= c->lds_per_block;  // fewer waves may leave room for the fine table
         const int BLOCK_POP = 64 * (int)W;
         a.pop_tiles = G;
+        a.pop_groups = 4 / G;
         a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
         a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
         const size_t lds_pop = waves_bytes + (fine ? fixed_fine : fixed_coarse);
