@@ -394,10 +394,50 @@ template <int S, int A> PSH_DEV double quadr_cost(const psh_task& t, const doubl
     return cs + ca;
 }
 
-// ScaledExpQuadrErrRewFcn.reset: c_max from the CURRENT (randomized) bounds of this environment
-template <int KIND> PSH_DEV double task_c_max(const Env<KIND>& e, const psh_task& t) {
+// The shape of the task each simulation creates by default (_create_task of the classes cited at the top): which
+// reward function, which error components are taken modulo, which final reward.  A kernel built for this shape (FIXT)
+// has these decisions made at compile time and takes Q and R as diagonal; the host selects it when the caller's
+// psh_task has exactly this shape (task_has_default_shape), the numbers (weights, desired state, factors) still come
+// from the descriptor.
+template <int KIND> struct TaskShape;
+template <> struct TaskShape<PSH_ENV_QQ> { static constexpr int rew = PSH_REW_EXP_QUADR, radial_mask = 2, fin = 0; };
+template <> struct TaskShape<PSH_ENV_QCP_SU> { static constexpr int rew = PSH_REW_SWINGUP, radial_mask = 2, fin = PSH_FIN_ENABLED | PSH_FIN_ALWAYS_NEGATIVE; };
+template <> struct TaskShape<PSH_ENV_QCP_ST> { static constexpr int rew = PSH_REW_QUADR, radial_mask = 2, fin = PSH_FIN_ENABLED | PSH_FIN_STATE_DEPENDENT | PSH_FIN_TIME_DEPENDENT; };
+template <> struct TaskShape<PSH_ENV_QBB> { static constexpr int rew = PSH_REW_SCALED_EXP_QUADR, radial_mask = 0, fin = 0; };
+template <> struct TaskShape<PSH_ENV_BOB> { static constexpr int rew = PSH_REW_SCALED_EXP_QUADR, radial_mask = 0, fin = 0; };
+template <> struct TaskShape<PSH_ENV_OMO> { static constexpr int rew = PSH_REW_QUADR, radial_mask = 0, fin = PSH_FIN_ENABLED | PSH_FIN_ALWAYS_NEGATIVE; };
+template <> struct TaskShape<PSH_ENV_PEND> { static constexpr int rew = PSH_REW_EXP_QUADR, radial_mask = 2, fin = 0; };
+template <> struct TaskShape<PSH_ENV_QQ_ST> { static constexpr int rew = PSH_REW_EXP_QUADR, radial_mask = 2, fin = 0; };
+
+template <int KIND> static inline bool task_has_default_shape(const psh_task& t) {
+    using Sh = TaskShape<KIND>;
     constexpr int S = Env<KIND>::S, A = Env<KIND>::A;
-    if (t.rew_kind != PSH_REW_SCALED_EXP_QUADR) return 0.;
+    if (t.rew_kind != Sh::rew || t.final_mode != Sh::fin) return false;
+    if ((t.radial != 0) != (Sh::radial_mask != 0) || (t.radial && t.radial_mask != Sh::radial_mask)) return false;
+    if (Sh::rew == PSH_REW_SWINGUP) return t.idx_x == 0 && t.idx_th == 1;
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j)
+            if (i != j && t.Q[i * S + j] != 0.) return false;
+    for (int i = 0; i < A; ++i)
+        for (int j = 0; j < A; ++j)
+            if (i != j && t.R[i * A + j] != 0.) return false;
+    return true;
+}
+
+// e^T diag(Q) e + a^T diag(R) a, accumulated in the order of the dense form with its zero terms left out
+template <int S, int A> PSH_DEV double quadr_cost_diag(const psh_task& t, const double* es, const double* ea) {
+    double cs = 0., ca = 0.;
+#pragma unroll
+    for (int i = 0; i < S; ++i) cs += es[i] * (t.Q[i * S + i] * es[i]);
+#pragma unroll
+    for (int i = 0; i < A; ++i) ca += ea[i] * (t.R[i * A + i] * ea[i]);
+    return cs + ca;
+}
+
+// ScaledExpQuadrErrRewFcn.reset: c_max from the CURRENT (randomized) bounds of this environment
+template <int KIND, bool FIXT = false> PSH_DEV double task_c_max(const Env<KIND>& e, const psh_task& t) {
+    constexpr int S = Env<KIND>::S, A = Env<KIND>::A;
+    if ((FIXT ? TaskShape<KIND>::rew : t.rew_kind) != PSH_REW_SCALED_EXP_QUADR) return 0.;
     double lo[S], hi[S], alo[A], ahi[A], om[S], am[A];
     e.state_bounds(lo, hi);
     e.act_bounds(alo, ahi);
@@ -405,18 +445,19 @@ template <int KIND> PSH_DEV double task_c_max(const Env<KIND>& e, const psh_task
     for (int i = 0; i < S; ++i) om[i] = fmax(fabs(lo[i]), fabs(hi[i]));
 #pragma unroll
     for (int i = 0; i < A; ++i) am[i] = fmax(fabs(alo[i]), fabs(ahi[i]));
-    return -1.0 * log(t.min_rew) / quadr_cost<S, A>(t, om, am);
+    return -1.0 * log(t.min_rew) / (FIXT ? quadr_cost_diag<S, A>(t, om, am) : quadr_cost<S, A>(t, om, am));
 }
 
-template <int KIND> PSH_DEV double step_rew(const psh_task& t, double c_max, const double* state, const double* act) {
+template <int KIND, bool FIXT = false> PSH_DEV double step_rew(const psh_task& t, double c_max, const double* state, const double* act) {
     constexpr int S = Env<KIND>::S, A = Env<KIND>::A;
+    using Sh = TaskShape<KIND>;
     double es[S], ea[A];
 #pragma unroll
     for (int i = 0; i < S; ++i) es[i] = t.state_des[i] - state[i];
-    if (t.radial) {
+    if (FIXT ? Sh::radial_mask != 0 : t.radial != 0) {
 #pragma unroll
         for (int i = 0; i < S; ++i)
-            if (t.radial_mask & (1 << i)) es[i] = psh_fmod(es[i], t.mod[i]);
+            if ((FIXT ? Sh::radial_mask : t.radial_mask) & (1 << i)) es[i] = psh_fmod(es[i], t.mod[i]);
         // the +-pi fold touches EVERY error component (desired_state.py:125-126), velocities included
 #pragma unroll
         for (int i = 0; i < S; ++i) {
@@ -428,21 +469,21 @@ template <int KIND> PSH_DEV double step_rew(const psh_task& t, double c_max, con
     }
 #pragma unroll
     for (int i = 0; i < A; ++i) ea[i] = -act[i];
-    switch (t.rew_kind) {
-    case PSH_REW_QUADR: return -quadr_cost<S, A>(t, es, ea);
-    case PSH_REW_EXP_QUADR: return psh_exp(-quadr_cost<S, A>(t, es, ea));
-    case PSH_REW_SCALED_EXP_QUADR: return psh_exp(-c_max * quadr_cost<S, A>(t, es, ea));
-    default: {  // PSH_REW_SWINGUP
+    const int kind = FIXT ? Sh::rew : t.rew_kind;
+    if (kind == PSH_REW_SWINGUP) {
         double eth = es[0], ex = es[0];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            eth = (i == t.idx_th) ? es[i] : eth;
-            ex = (i == t.idx_x) ? es[i] : ex;
+            eth = (i == (FIXT ? 1 : t.idx_th)) ? es[i] : eth;
+            ex = (i == (FIXT ? 0 : t.idx_x)) ? es[i] : ex;
         }
         const double cost_pole = t.swingup[3] * (eth * eth) + log(eth * eth + t.swingup[4]);
         return -t.swingup[0] * cost_pole - t.swingup[1] * fabs(ex) - t.swingup[2] * (ea[0] * ea[0]) + 10;
     }
-    }
+    const double cost = FIXT ? quadr_cost_diag<S, A>(t, es, ea) : quadr_cost<S, A>(t, es, ea);
+    if (kind == PSH_REW_QUADR) return -cost;
+    if (kind == PSH_REW_EXP_QUADR) return psh_exp(-cost);
+    return psh_exp(-c_max * cost);
 }
 
 // BoxSpace.contains on the state: inclusive bounds; a NaN makes the reference raise, here it sets `nan`
@@ -460,8 +501,8 @@ template <int KIND> PSH_DEV bool state_inside(const Env<KIND>& e, bool& nan) {
 }
 
 // FinalRewTask.compute_final_rew for a FAILED state (success never happens in these tasks)
-template <int KIND> PSH_DEV double final_rew_failed(const Env<KIND>& e, const psh_task& t, double c_max, int remaining) {
-    const int m = t.final_mode;
+template <int KIND, bool FIXT = false> PSH_DEV double final_rew_failed(const Env<KIND>& e, const psh_task& t, double c_max, int remaining) {
+    const int m = FIXT ? TaskShape<KIND>::fin : t.final_mode;
     const bool ap = m & PSH_FIN_ALWAYS_POSITIVE, an = m & PSH_FIN_ALWAYS_NEGATIVE;
     const bool sd = m & PSH_FIN_STATE_DEPENDENT, td = m & PSH_FIN_TIME_DEPENDENT;
     if (ap) return (an ? __builtin_nan("") : 0.);
@@ -470,19 +511,19 @@ template <int KIND> PSH_DEV double final_rew_failed(const Env<KIND>& e, const ps
     double zero[Env<KIND>::A];
 #pragma unroll
     for (int i = 0; i < Env<KIND>::A; ++i) zero[i] = 0.;
-    const double r = fabs(step_rew<KIND>(t, c_max, e.s, zero));
+    const double r = fabs(step_rew<KIND, FIXT>(t, c_max, e.s, zero));
     if (!td) return -1. * t.final_factor * r;
     return an ? __builtin_nan("") : -1. * remaining * r;
 }
 
 // SimPyEnv.step (base.py:177-201).  act_io: in = raw action; out = the action as the caller's array holds it
 // after the call (QBB dead zone is written through when the action was inside its bounds, spaces/box.py:144-148).
-template <int KIND>
+template <int KIND, bool FIXT = false>
 PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr_step, int& yielded, double* act_io,
                         double dt, int max_steps, bool inf_steps, bool simplified, bool& done, int& st) {
     constexpr int A = Env<KIND>::A;
     const int remaining = inf_steps ? 0 : max_steps - (curr_step + 1);
-    double rew = step_rew<KIND>(t, c_max, e.s, act_io);
+    double rew = step_rew<KIND, FIXT>(t, c_max, e.s, act_io);
     double alo[A], ahi[A], a[A];
     e.act_bounds(alo, ahi);
     bool inside = true;
@@ -502,9 +543,9 @@ PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr
     if (!inf_steps && curr_step >= max_steps) { d = true; st |= PSH_ST_TIMEOUT; }
     if (failed) st |= PSH_ST_FAILED;
     if (nan) st |= PSH_ST_NAN;
-    if (d && (t.final_mode & PSH_FIN_ENABLED) && !yielded) {
+    if (d && ((FIXT ? TaskShape<KIND>::fin : t.final_mode) & PSH_FIN_ENABLED) && !yielded) {
         yielded = 1;
-        if (failed) rew += final_rew_failed<KIND>(e, t, c_max, remaining);
+        if (failed) rew += final_rew_failed<KIND, FIXT>(e, t, c_max, remaining);
     }
     done = d;
     return rew;

@@ -113,7 +113,7 @@ template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t
 
 // WRAP = true adds the fused environment wrappers (psh_wrappers) around the simulation; the bare variant carries
 // none of that code or state.
-template <int KIND, bool WRAP> struct Lane {
+template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
     using E = Env<KIND>;
     E e;
     double c_max, ret;
@@ -214,7 +214,7 @@ template <int KIND, bool WRAP> struct Lane {
         if (a.pol.policy_index) bad_index = bad_index || (unsigned)a.pol.policy_index[i] >= (unsigned)a.pol.n_policies;
         const DpCol p{a.domain_param, a.ld_dp, col};
         e.setup(p);
-        c_max = task_c_max<KIND>(e, task);
+        c_max = task_c_max<KIND, FIXT>(e, task);
         double init[E::S];
         for (int r = 0; r < E::S; ++r) init[r] = (r < a.init_dim) ? a.init_state[r * a.ld_init + i] : 0.;
         if constexpr (KIND == PSH_ENV_QBB) {
@@ -363,7 +363,7 @@ template <int KIND, bool WRAP> struct Lane {
                 }
             }
         } else {
-            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
+            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
@@ -405,7 +405,12 @@ template <int KIND, bool WRAP> struct Lane {
 // ------------------------------------------------------------------------------------- LinearPolicy rollouts
 // PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] (or, in
 // population mode, row i / policy_group) of params.
-template <int KIND, bool PER_ENV, bool WRAP>
+// SIMPLE: the FeatureStack holds const_feat / identity_feat only (the usual LinearPolicy): the variant carries none of
+// the other feature functions' code, which the generic kernel drags through its instruction cache and whose dispatch
+// costs scalar instructions on every step (the scalar unit of a CU, shared by its four SIMDs, is what bounds the cheap
+// simulations).
+// FIXT: the task has the default shape of this simulation (TaskShape), decided at compile time.
+template <int KIND, bool PER_ENV, bool WRAP, bool SIMPLE = false, bool FIXT = false>
 __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_LIN_FEAT;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
     }
     stage_task(a, lds_lin + W_DOUBLES);
     __syncthreads();
-    Lane<KIND, WRAP> L;
+    Lane<KIND, WRAP, FIXT> L;
     L.init();
     const double* w = lds_w;
     long w_env = -1;
@@ -448,6 +453,14 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n];
                 n += 1;
+            } else if (SIMPLE) {
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) {
+                    if (WRAP && q >= Oe) break;
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * obs[q];
+                }
+                n += Oe;
             } else if (id == PSH_FEAT_MULT) {  // MultFeat (policies/features.py:143-167)
                 const int arg = a.pol.feat_arg[f];
                 double v = 1.0;  // 1 * x is exact
@@ -1060,11 +1073,19 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;
-        if (per_env)
-            return wrapped ? launch_persistent(c, k_rollout_linear<KIND, true, true>, 256, 0, a, E::A, has_delay, st)
-                           : launch_persistent(c, k_rollout_linear<KIND, true, false>, 256, 0, a, E::A, false, st);
-        return wrapped ? launch_persistent(c, k_rollout_linear<KIND, false, true>, 256, 0, a, E::A, has_delay, st)
-                       : launch_persistent(c, k_rollout_linear<KIND, false, false>, 256, 0, a, E::A, false, st);
+        bool simple = true;
+        for (int f = 0; f < p.n_feats; ++f) simple = simple && (p.feats[f] == PSH_FEAT_CONST || p.feats[f] == PSH_FEAT_IDENTITY);
+        // the usual case gets a kernel of its own: bare simulation, const / identity features, the simulation's default task
+        const bool fixt = simple && !wrapped && task_has_default_shape<KIND>(d->task);
+#define PSH_LAUNCH_LIN(PER_ENV_, WRAP_)                                                                                     \
+    (simple ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st) \
+            : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st))
+        if (fixt)
+            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, false, true, true>, 256, 0, a, E::A, false, st)
+                           : launch_persistent(c, k_rollout_linear<KIND, false, false, true, true>, 256, 0, a, E::A, false, st);
+        if (per_env) return wrapped ? PSH_LAUNCH_LIN(true, true) : PSH_LAUNCH_LIN(true, false);
+        return wrapped ? PSH_LAUNCH_LIN(false, true) : PSH_LAUNCH_LIN(false, false);
+#undef PSH_LAUNCH_LIN
     }
     if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
     if (p.n_hidden < 1 || p.n_hidden > PSH_MAX_HIDDEN) { set_err(c, "FNNPolicy needs 1..4 hidden layers"); return PSH_ERR_ARG; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ Rollout-kernel throughput for every env kind, LinearPolicy and FNNPolicy 64x64 (returns only, T = 600 or the env's
 default horizon): env-steps/s from the kernel's own HIP-event duration.
-Usage: python tools/perf_envs.py [n_envs] [linear|fnn|''] [weight scale]; scale 0 keeps most envs alive for all T steps. """
+Usage: python tools/perf_envs.py [n_envs] [linear|fnn|''] [weight scale] [features]; scale 0 keeps most envs alive for all T steps. """
 import os
 import sys
 
@@ -16,6 +16,7 @@ from tests import cases  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 only = sys.argv[2] if len(sys.argv) > 2 else ''
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
+feats = tuple(sys.argv[4].split(',')) if len(sys.argv) > 4 else ('const', 'identity', 'squared')   # LinearPolicy feature stack
 eng = get_engine(0)
 names = {abi.ENV_QQ: 'QQ', abi.ENV_QCP_SU: 'QCP_SU', abi.ENV_QCP_ST: 'QCP_ST', abi.ENV_QBB: 'QBB', abi.ENV_BOB: 'BOB',
          abi.ENV_OMO: 'OMO', abi.ENV_PEND: 'PEND', abi.ENV_QQ_ST: 'QQ_ST'}
@@ -23,7 +24,7 @@ for kind in cases.KINDS:
     for pol in ('linear', 'fnn'):
         if only and only != pol:
             continue
-        case = cases.make_case(kind, n, seed=kind, policy=pol, scale=scale, **(dict(hidden=(64, 64)) if pol == 'fnn' else {}))
+        case = cases.make_case(kind, n, seed=kind, policy=pol, scale=scale, **(dict(hidden=(64, 64)) if pol == 'fnn' else dict(feats=feats)))
         T = 600
         args = (kind, case['dt'], T, case['task_c'], case['ps'], torch.as_tensor(case['params'], device=eng.device),
                 torch.as_tensor(case['init'], device=eng.device), torch.as_tensor(case['dp'], device=eng.device))

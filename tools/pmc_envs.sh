@@ -1,15 +1,16 @@
 #!/bin/bash
 # Dynamic instruction counts of the LinearPolicy rollout kernels (tools/perf_envs.py with zero weights, so that the
 # rollouts run their full horizon): three counter passes, per-kernel sums divided by the number of launches.
-# Usage: tools/pmc_envs.sh <tag> [n_envs] [linear|fnn]
+# Usage: tools/pmc_envs.sh <tag> [n_envs] [linear|fnn] [features of the LinearPolicy, e.g. identity]
 set -e
 out=gpurun_out/pmc_envs_$1
 n=${2:-1048576}
 pol=${3:-linear}
+feats=${4:-}
 mkdir -p $out
-timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_INSTS_LDS -d $out -o a --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 > $out/a.log 2>&1
-timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $out -o b --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 > $out/b.log 2>&1
-timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC -d $out -o c --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 > $out/c.log 2>&1
+timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_INSTS_LDS -d $out -o a --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 $feats > $out/a.log 2>&1
+timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $out -o b --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 $feats > $out/b.log 2>&1
+timeout -s KILL 170 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC -d $out -o c --output-format csv -- python3 tools/perf_envs.py $n $pol 0.0 $feats > $out/c.log 2>&1
 python3 - $out $pol <<'PY'
 import csv, sys, collections, re
 out = sys.argv[1]
