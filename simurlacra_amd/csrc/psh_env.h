@@ -119,7 +119,7 @@ template <> struct Env<PSH_ENV_QQ_ST> : EnvQQ<true> {};
 template <> struct Env<PSH_ENV_PEND> {
     static constexpr int S = 2, O = 3, A = 1, P = 5, I = 2, X = 0;
     double s[2];
-    double hmgl, d_pole, tau_max, inertia;  // 0.5 m g l, damping, torque limit, m l^2 / 3
+    double hmgl, d_pole, tau_max, inertia, r_inertia;  // 0.5 m g l, damping, torque limit, m l^2 / 3 and its reciprocal
     double sth, cth;
 
     PSH_DEV void setup(const DpCol& p) {
@@ -127,6 +127,7 @@ template <> struct Env<PSH_ENV_PEND> {
         d_pole = p[3]; tau_max = p[4];
         hmgl = 0.5 * m_pole * g * l_pole;
         inertia = m_pole * (l_pole * l_pole) / 3.;
+        r_inertia = 1. / inertia;
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const { lo[0] = lo[1] = -4 * PSH_PI; hi[0] = hi[1] = 4 * PSH_PI; }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -tau_max; hi[0] = tau_max; }
@@ -138,7 +139,7 @@ template <> struct Env<PSH_ENV_PEND> {
     PSH_DEV void reset(const double* init, int, bool) { s[0] = init[0]; s[1] = init[1]; refresh(); }
     PSH_DEV void observe(double* o) const { o[0] = sth; o[1] = cth; o[2] = s[1]; }
     PSH_DEV void dynamics(double* act, double dt, bool) {  // pendulum.py:49-61
-        const double th_ddot = (act[0] - hmgl * sth - d_pole * s[1]) / inertia;
+        const double th_ddot = psh_div_by(act[0] - hmgl * sth - d_pole * s[1], inertia, r_inertia);
         s[1] += th_ddot * dt;
         s[0] += s[1] * dt;
         refresh();
@@ -149,7 +150,7 @@ template <> struct Env<PSH_ENV_PEND> {
 template <int KIND> struct EnvQCP {
     static constexpr int S = 4, O = 5, A = 1, P = 14, I = 4, X = 0;
     double s[4];
-    double g, eta_m, K_g_k_m_over_r, B_pole, B_eq, ml, l_rail, f_gain, a11, a22, mlg;
+    double g, eta_m, K_g_k_m_over_r, B_pole, B_eq, ml, l_rail, f_gain, a11, r_a11, a22, mlg;
     double sth, cth;
 
     PSH_DEV void setup(const DpCol& p) {
@@ -165,6 +166,7 @@ template <int KIND> struct EnvQCP {
         ml = m_pole * l_pole;
         mlg = ml * g;
         a11 = m_pole + J_eq;
+        r_a11 = 1. / a11;
         a22 = J_pole + m_pole * (l_pole * l_pole);
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const {
@@ -201,10 +203,11 @@ template <int KIND> struct EnvQCP {
         const double b2 = -B_pole * th_dot - mlg * sth;
         // 2x2 solve.  The reference goes through LAPACK's pivoted LU; a11 = m_pole + J_eq always dominates
         // a21 = m_pole*l_pole*cos(th) for physical parameters, so the elimination order is the same.
-        const double l21 = a12 / a11;
+        // (a11 is a constant of the environment: its quotients take the stored reciprocal and one correction step)
+        const double l21 = psh_div_by(a12, a11, r_a11);
         const double u22 = a22 - l21 * a12;
-        const double x2 = (b2 - l21 * b1) / u22;
-        const double x1 = (b1 - x2 * a12) / a11;
+        const double x2 = psh_div_moderate(b2 - l21 * b1, u22);
+        const double x1 = psh_div_by(b1 - x2 * a12, a11, r_a11);
         s[2] += x1 * dt; s[3] += x2 * dt;
         s[0] += s[2] * dt; s[1] += s[3] * dt;
         refresh();
@@ -241,7 +244,7 @@ template <> struct Env<PSH_ENV_QBB> {
     double s[8];
     double plate[2];  // hidden plate angles (forward-Euler state, set by IK at reset)
     double g, m_ball, r_ball, l_plate, r_arm, c_frict, Vxp, Vxn, Vyp, Vyn, off_x, off_y;
-    double J_ball, J_eq, c_kin, A_m, B_eq_v, zeta;
+    double J_ball, J_eq, r_J_eq, c_kin, A_m, B_eq_v, zeta, r_zeta;
 
     PSH_DEV void setup(const DpCol& p) {
         g = p[0]; m_ball = p[1]; r_ball = p[2]; l_plate = p[3]; r_arm = p[4];
@@ -253,6 +256,7 @@ template <> struct Env<PSH_ENV_QBB> {
         A_m = eta_g * K_g * eta_m * k_m / R_m;
         B_eq_v = eta_g * (K_g * K_g) * eta_m * (k_m * k_m) / R_m + B_eq;
         zeta = m_ball * (r_ball * r_ball) + J_ball;
+        r_J_eq = 1. / J_eq; r_zeta = 1. / zeta;
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const {
         const double m[8] = {PSH_PI / 4., PSH_PI / 4., l_plate / 2., l_plate / 2., 5 * PSH_PI, 5 * PSH_PI, 0.5, 0.5};
@@ -282,26 +286,27 @@ template <> struct Env<PSH_ENV_QBB> {
         }
         const double th_x = s[0] + off_x, th_y = s[1] + off_y, x = s[2], y = s[3];
         const double th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
-        const double th_x_ddot = (A_m * act[0] - B_eq_v * th_x_dot) / J_eq;
-        const double th_y_ddot = (A_m * act[1] - B_eq_v * th_y_dot) / J_eq;
+        const double th_x_ddot = psh_div_by(A_m * act[0] - B_eq_v * th_x_dot, J_eq, r_J_eq);
+        const double th_y_ddot = psh_div_by(A_m * act[1] - B_eq_v * th_y_dot, J_eq, r_J_eq);
         double sx, cx, sy, cy, sa, ca, sb, cb;
         psh_sincos(th_x, &sx, &cx); psh_sincos(th_y, &sy, &cy);
         psh_sincos(plate[0], &sa, &ca); psh_sincos(plate[1], &sb, &cb);
-        const double a_dot = c_kin * th_x_dot * cx / ca;
-        const double b_dot = c_kin * -th_y_dot * cy / cb;  // cos(-th_y) = cos(th_y)
+        const double rca = psh_rcp_refined(ca), rcb = psh_rcp_refined(cb);  // the plate stays far from vertical
+        const double a_dot = psh_div_by(c_kin * th_x_dot * cx, ca, rca);
+        const double b_dot = psh_div_by(c_kin * -th_y_dot * cy, cb, rcb);  // cos(-th_y) = cos(th_y)
         const double r2 = r_ball * r_ball;
         double x_ddot, y_ddot;
         if (simplified) {
-            x_ddot = c_kin * m_ball * g * r2 * sx / zeta;
-            y_ddot = c_kin * m_ball * g * r2 * sy / zeta;
+            x_ddot = psh_div_by(c_kin * m_ball * g * r2 * sx, zeta, r_zeta);
+            y_ddot = psh_div_by(c_kin * m_ball * g * r2 * sy, zeta, r_zeta);
         } else {
-            const double a_ddot = 1. / ca * (c_kin * (th_x_ddot * cx - (th_x_dot * th_x_dot) * sx) + (a_dot * a_dot) * sa);
+            const double a_ddot = rca * (c_kin * (th_x_ddot * cx - (th_x_dot * th_x_dot) * sx) + (a_dot * a_dot) * sa);
             // sin(-th_y) = -sin(th_y)
-            const double b_ddot = 1. / cb * (c_kin * (-th_y_ddot * cy - (th_y_dot * th_y_dot) * (-sy)) + (b_dot * b_dot) * sb);
-            x_ddot = (-c_frict * x_dot * r2 - J_ball * r_ball * a_ddot + m_ball * x * (a_dot * a_dot) * r2 +
-                      c_kin * m_ball * g * r2 * sx) / zeta;
-            y_ddot = (-c_frict * y_dot * r2 - J_ball * r_ball * b_ddot + m_ball * y * (b_dot * b_dot) * r2 +
-                      c_kin * m_ball * g * r2 * sy) / zeta;
+            const double b_ddot = rcb * (c_kin * (-th_y_ddot * cy - (th_y_dot * th_y_dot) * (-sy)) + (b_dot * b_dot) * sb);
+            x_ddot = psh_div_by(-c_frict * x_dot * r2 - J_ball * r_ball * a_ddot + m_ball * x * (a_dot * a_dot) * r2 +
+                                c_kin * m_ball * g * r2 * sx, zeta, r_zeta);
+            y_ddot = psh_div_by(-c_frict * y_dot * r2 - J_ball * r_ball * b_ddot + m_ball * y * (b_dot * b_dot) * r2 +
+                                c_kin * m_ball * g * r2 * sy, zeta, r_zeta);
         }
         s[4] += th_x_ddot * dt; s[5] += th_y_ddot * dt; s[6] += x_ddot * dt; s[7] += y_ddot * dt;
         for (int i = 0; i < 4; ++i) s[i] += s[4 + i] * dt;
@@ -313,7 +318,7 @@ template <> struct Env<PSH_ENV_QBB> {
 template <> struct Env<PSH_ENV_BOB> {
     static constexpr int S = 4, O = 4, A = 1, P = 8, I = 4, X = 0;
     double s[4];
-    double g, m_ball, l_beam, c_frict, ang_offset, J_beam, zeta_ball;
+    double g, m_ball, l_beam, c_frict, ang_offset, J_beam, zeta_ball, r_zeta_ball;
 
     PSH_DEV void setup(const DpCol& p) {
         g = p[0]; m_ball = p[1];
@@ -322,6 +327,7 @@ template <> struct Env<PSH_ENV_BOB> {
         const double J_ball = 2. / 5 * m_ball * (r_ball * r_ball);
         J_beam = 1. / 12 * m_beam * ((l_beam * l_beam) + (d_beam * d_beam));
         zeta_ball = m_ball + J_ball / (r_ball * r_ball);
+        r_zeta_ball = 1. / zeta_ball;
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const {
         const double m[4] = {l_beam / 2., PSH_PI / 4., 10., PSH_PI};
@@ -340,8 +346,8 @@ template <> struct Env<PSH_ENV_BOB> {
         double sa, ca;
         psh_sincos(a, &sa, &ca);
         const double zeta_beam = m_ball * (x * x) + J_beam;
-        const double x_ddot = (-c_frict * x_dot + m_ball * x * (a_dot * a_dot) - m_ball * g * sa) / zeta_ball;
-        const double a_ddot = (act[0] - 2. * m_ball * x * x_dot * a_dot - m_ball * g * ca * x) / zeta_beam;
+        const double x_ddot = psh_div_by(-c_frict * x_dot + m_ball * x * (a_dot * a_dot) - m_ball * g * sa, zeta_ball, r_zeta_ball);
+        const double a_ddot = psh_div_moderate(act[0] - 2. * m_ball * x * x_dot * a_dot - m_ball * g * ca * x, zeta_beam);
         s[2] += x_ddot * dt; s[3] += a_ddot * dt;
         s[0] += s[2] * dt; s[1] += s[3] * dt;
     }
@@ -351,13 +357,15 @@ template <> struct Env<PSH_ENV_BOB> {
 template <> struct Env<PSH_ENV_OMO> {
     static constexpr int S = 2, O = 2, A = 1, P = 3, I = 2, X = 0;
     double s[2];
-    double m, k, omega, zeta;
+    double k, r_m, a0, a1;  // spring constant (the action bound), 1/m and the second row of the system matrix
 
     PSH_DEV void setup(const DpCol& p) {
-        m = p[0]; k = p[1];
-        const double d = p[2];
-        omega = sqrt(k / m);
-        zeta = d / (2. * sqrt(m * k));
+        const double m = p[0], d = p[2];
+        k = p[1];
+        const double omega = sqrt(k / m), zeta = d / (2. * sqrt(m * k));  // one_mass_oscillator.py:55-57
+        r_m = 1. / m;
+        a0 = -(omega * omega);
+        a1 = -2. * zeta * omega;
     }
     PSH_DEV void state_bounds(double* lo, double* hi) const { lo[0] = -1.; hi[0] = 1.; lo[1] = -10.; hi[1] = 10.; }
     PSH_DEV void act_bounds(double* lo, double* hi) const { lo[0] = -k; hi[0] = k; }
@@ -367,7 +375,7 @@ template <> struct Env<PSH_ENV_OMO> {
     PSH_DEV void observe(double* o) const { o[0] = s[0]; o[1] = s[1]; }
     PSH_DEV void dynamics(double* act, double dt, bool) {
         const double sd0 = s[1];
-        const double sd1 = -(omega * omega) * s[0] + -2. * zeta * omega * s[1] + 1. / m * act[0];
+        const double sd1 = a0 * s[0] + a1 * s[1] + r_m * act[0];
         s[0] = s[0] + sd0 * dt;
         s[1] = s[1] + sd1 * dt;
     }
@@ -526,15 +534,21 @@ PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr
     double rew = step_rew<KIND, FIXT>(t, c_max, e.s, act_io);
     double alo[A], ahi[A], a[A];
     e.act_bounds(alo, ahi);
-    bool inside = true;
+    // BoxSpace.project (spaces/box.py:144-148): an action inside its bounds is passed on as it is (the caller's array, which
+    // only QBallBalancerSim writes to), any other one is clipped; clipping leaves an inside action unchanged
 #pragma unroll
-    for (int i = 0; i < A; ++i) inside = inside && (act_io[i] >= alo[i]) && (act_io[i] <= ahi[i]);
+    for (int i = 0; i < A; ++i) a[i] = psh_clip(act_io[i], alo[i], ahi[i]);
+    if constexpr (KIND == PSH_ENV_QBB) {
+        bool inside = true;
 #pragma unroll
-    for (int i = 0; i < A; ++i) a[i] = inside ? act_io[i] : fmin(fmax(act_io[i], alo[i]), ahi[i]);
-    e.dynamics(a, dt, simplified);
-    if (KIND == PSH_ENV_QBB && inside) {
+        for (int i = 0; i < A; ++i) inside = inside && (act_io[i] >= alo[i]) && (act_io[i] <= ahi[i]);
+        e.dynamics(a, dt, simplified);
+        if (inside) {
 #pragma unroll
-        for (int i = 0; i < A; ++i) act_io[i] = a[i];
+            for (int i = 0; i < A; ++i) act_io[i] = a[i];
+        }
+    } else {
+        e.dynamics(a, dt, simplified);
     }
     curr_step += 1;
     bool nan = false;

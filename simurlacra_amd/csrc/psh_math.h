@@ -26,6 +26,15 @@ PSH_MATH double psh_div_moderate(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// min(max(x, lo), hi) for an x that is not a NaN.  As instructions of their own: fmin/fmax first canonicalise each operand
+// (a v_max_f64 x, x per operand) because the kernels run in IEEE mode.
+PSH_MATH double psh_clip(double x, double lo, double hi) {
+    double y;
+    asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(x), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(y) : "v"(y), "v"(hi));
+    return y;
+}
+
 // n / d given r ~ 1/d (relative error far below 2^-26): product plus one residual correction
 PSH_MATH double psh_div_by(double n, double d, double r) {
     const double q = n * r;

@@ -405,10 +405,10 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
 // ------------------------------------------------------------------------------------- LinearPolicy rollouts
 // PER_ENV = false: one weight set, staged in LDS and broadcast; true: env i reads row policy_index[i] (or, in
 // population mode, row i / policy_group) of params.
-// SIMPLE: the FeatureStack holds const_feat / identity_feat only (the usual LinearPolicy): the variant carries none of
-// the other feature functions' code, which the generic kernel drags through its instruction cache and whose dispatch
-// costs scalar instructions on every step (the scalar unit of a CU, shared by its four SIMDs, is what bounds the cheap
-// simulations).
+// SIMPLE: the FeatureStack is [identity_feat] or [const_feat, identity_feat] (the usual LinearPolicy): a dot product on
+// the observation with the weights in registers; the variant carries none of the feature functions' code, whose
+// dispatch costs scalar instructions on every step (the scalar unit of a CU, shared by its four SIMDs, is what bounds
+// the cheap simulations).
 // FIXT: the task has the default shape of this simulation (TaskShape), decided at compile time.
 template <int KIND, bool PER_ENV, bool WRAP, bool SIMPLE = false, bool FIXT = false>
 __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
@@ -430,20 +430,51 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
     L.init();
     const double* w = lds_w;
     long w_env = -1;
+    // SIMPLE: the weights live in registers, [r][0] = what the const feature contributes (0 without one), [r][1 + q] =
+    // the weight of observation q
+    double wreg[SIMPLE ? E::A : 1][SIMPLE ? E::O + 1 : 1];
+    auto load_wreg = [&](const double* src) {
+        if constexpr (SIMPLE) {
+            const int off = a.pol.feats[0] == PSH_FEAT_CONST ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) {
+                wreg[r][0] = off ? 0. + src[r * F] : 0.;
+#pragma unroll
+                for (int q = 0; q < E::O; ++q) wreg[r][1 + q] = (!WRAP || q < Oe) ? src[r * F + off + q] : 0.;
+            }
+        }
+    };
+    if (SIMPLE && !PER_ENV) load_wreg(lds_w);
     for (;;) {
         asm volatile("" ::: "memory");  // keep the LDS constants out of registers across iterations
-        L.template turnover<8>(a, task, wrap);
-        if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
-        if (L.i < 0 || !L.live) continue;
-        if (PER_ENV && w_env != L.i) {
-            const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
-                                                : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
-            w = a.pol.params + row * a.pol.num_param;
-            w_env = L.i;
+        // as long as every lane of the wave is in the middle of an episode there is nothing to exchange
+        if (!__all(L.live)) {
+            L.template turnover<8>(a, task, wrap);
+            if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
+            if (!L.live) continue;        // (a lane without an env is not live)
+            if (PER_ENV && w_env != L.i) {
+                const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
+                                                    : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
+                w = a.pol.params + row * a.pol.num_param;
+                w_env = L.i;
+                load_wreg(w);
+            }
         }
         double obs[E::O], act[E::A];
         L.pre_policy(a, wrap, obs);
         if (!L.live) continue;
+        if constexpr (SIMPLE) {
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) act[r] = wreg[r][0];
+#pragma unroll
+            for (int q = 0; q < E::O; ++q) {
+                if (WRAP && q >= Oe) break;
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act[r] += wreg[r][1 + q] * obs[q];
+            }
+            L.post_policy(a, task, wrap, act);
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < E::A; ++r) act[r] = 0.;
         int n = 0;
@@ -453,14 +484,6 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n];
                 n += 1;
-            } else if (SIMPLE) {
-#pragma unroll
-                for (int q = 0; q < E::O; ++q) {
-                    if (WRAP && q >= Oe) break;
-#pragma unroll
-                    for (int r = 0; r < E::A; ++r) act[r] += w[r * F + n + q] * obs[q];
-                }
-                n += Oe;
             } else if (id == PSH_FEAT_MULT) {  // MultFeat (policies/features.py:143-167)
                 const int arg = a.pol.feat_arg[f];
                 double v = 1.0;  // 1 * x is exact
@@ -1073,8 +1096,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;
-        bool simple = true;
-        for (int f = 0; f < p.n_feats; ++f) simple = simple && (p.feats[f] == PSH_FEAT_CONST || p.feats[f] == PSH_FEAT_IDENTITY);
+        const bool simple = (p.n_feats == 1 && p.feats[0] == PSH_FEAT_IDENTITY) ||
+                            (p.n_feats == 2 && p.feats[0] == PSH_FEAT_CONST && p.feats[1] == PSH_FEAT_IDENTITY);
         // the usual case gets a kernel of its own: bare simulation, const / identity features, the simulation's default task
         const bool fixt = simple && !wrapped && task_has_default_shape<KIND>(d->task);
 #define PSH_LAUNCH_LIN(PER_ENV_, WRAP_)                                                                                     \

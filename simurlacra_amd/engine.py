@@ -57,6 +57,7 @@ class Engine:
         if rc != 0:
             raise EngineError(f'psh_create({device}) failed with {rc}')
         self._h = h
+        self._lock = threading.Lock()
 
     def close(self):
         if getattr(self, '_h', None):
@@ -70,10 +71,14 @@ class Engine:
             pass
 
     # -- helpers
-    def _check(self, rc, what):
-        if rc != 0:
-            msg = self.lib.psh_last_error(self._h)
-            raise EngineError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
+    def _call(self, what, *args):
+        """ One library call on this context.  ctypes releases the GIL for the duration of the call and the context's
+        host-side state (scratch buffers, error message) is not thread safe, so the calls of one Engine are serialised. """
+        with self._lock:
+            rc = getattr(self.lib, what)(self._h, *args)
+            if rc != 0:
+                msg = self.lib.psh_last_error(self._h)
+                raise EngineError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -139,9 +144,9 @@ class Engine:
         d.obs, d.act, d.rew = _ptr(out.get('obs')), _ptr(out.get('act')), _ptr(out.get('rew'))
         d.stream = self._stream()
         if static_scratch:
-            self._check(self.lib.psh_rollout_static(self._h, C.byref(d)), 'psh_rollout_static')
+            self._call('psh_rollout_static', C.byref(d))
         else:
-            self._check(self.lib.psh_rollout(self._h, C.byref(d)), 'psh_rollout')
+            self._call('psh_rollout', C.byref(d))
         return out
 
     def last_rollout_ms(self) -> float:
@@ -170,7 +175,7 @@ class Engine:
         d = self._step_desc(env_kind, dt, max_steps, task_c, domain_param, flags, dp_index)
         d.n_envs, d.init_dim, d.init_state = N, init_state.shape[0], _ptr(init_state)
         d.state, d.curr_step, d.flags_io, d.obs, d.status = (_ptr(mem[k]) for k in ('state', 'curr_step', 'flags_io', 'obs', 'status'))
-        self._check(self.lib.psh_reset(self._h, C.byref(d)), 'psh_reset')
+        self._call('psh_reset', C.byref(d))
         return mem
 
     def step(self, env_kind, dt, max_steps, task_c, mem, act, domain_param, *, flags=0, dp_index=None):
@@ -184,7 +189,7 @@ class Engine:
         d.n_envs = N
         d.state, d.curr_step, d.flags_io, d.obs, d.status = (_ptr(mem[k]) for k in ('state', 'curr_step', 'flags_io', 'obs', 'status'))
         d.act, d.rew, d.done = _ptr(act), _ptr(rew), _ptr(done)
-        self._check(self.lib.psh_step(self._h, C.byref(d)), 'psh_step')
+        self._call('psh_step', C.byref(d))
         return mem['obs'], rew, done, mem['status']
 
     # -- randomization
@@ -204,7 +209,7 @@ class Engine:
             e.kind, e.row, e.roundint = q['kind'], q['row'], int(q.get('roundint', 0))
             e.a, e.b, e.c = float(q.get('a', 0.)), float(q.get('b', 0.)), float(q.get('c', 0.))
             e.clip_lo, e.clip_up = float(q.get('clip_lo', -np.inf)), float(q.get('clip_up', np.inf))
-        self._check(self.lib.psh_randomize(self._h, C.byref(d)), 'psh_randomize')
+        self._call('psh_randomize', C.byref(d))
         return out
 
     def sample_init(self, env_kind, n_envs, domain_param, seed, env_offset=0, dp_index=None):
@@ -214,14 +219,13 @@ class Engine:
         d.env_kind, d.n_envs, d.ld_dp, d.ld_out = env_kind, n_envs, domain_param.shape[1], n_envs
         d.seed, d.env_offset = int(seed), int(env_offset)
         d.domain_param, d.dp_index, d.out, d.stream = _ptr(domain_param), _ptr(dp_index), _ptr(out), self._stream()
-        self._check(self.lib.psh_sample_init(self._h, C.byref(d)), 'psh_sample_init')
+        self._call('psh_sample_init', C.byref(d))
         return out
 
     def qbb_ik(self, th, r_arm, l_plate):
         th, r_arm, l_plate = self.f64(th).reshape(-1), self.f64(r_arm).reshape(-1), self.f64(l_plate).reshape(-1)
         ang = torch.empty_like(th)
-        self._check(self.lib.psh_qbb_ik(self._h, th.numel(), _ptr(th), _ptr(r_arm), _ptr(l_plate), _ptr(ang),
-                                        self._stream()), 'psh_qbb_ik')
+        self._call('psh_qbb_ik', th.numel(), _ptr(th), _ptr(r_arm), _ptr(l_plate), _ptr(ang), self._stream())
         return ang
 
     def eval_math(self, fn: str, x, m=None):
@@ -230,16 +234,14 @@ class Engine:
         x = self.f64(x).reshape(-1)
         m = None if m is None else self.f64(m).reshape(-1)
         y = torch.empty_like(x)
-        self._check(self.lib.psh_eval_math(self._h, ids[fn], x.numel(), _ptr(x), _ptr(m), _ptr(y), self._stream()),
-                    'psh_eval_math')
+        self._call('psh_eval_math', ids[fn], x.numel(), _ptr(x), _ptr(m), _ptr(y), self._stream())
         return y
 
     def segment_mean(self, ret, group_size):
         ret = self.f64(ret).reshape(-1)
         n_groups = ret.numel()//group_size
         mean = torch.empty(n_groups, dtype=torch.float64, device=self.device)
-        self._check(self.lib.psh_segment_mean(self._h, n_groups, group_size, _ptr(ret), _ptr(mean), self._stream()),
-                    'psh_segment_mean')
+        self._call('psh_segment_mean', n_groups, group_size, _ptr(ret), _ptr(mean), self._stream())
         return mean
 
     def topk(self, values, k: int):
@@ -247,16 +249,15 @@ class Engine:
         values = self.f64(values).reshape(-1)
         idx = torch.empty(k, dtype=torch.int32, device=self.device)
         val = torch.empty(k, dtype=torch.float64, device=self.device)
-        self._check(self.lib.psh_topk(self._h, values.numel(), int(k), _ptr(values), _ptr(idx), _ptr(val), self._stream()),
-                    'psh_topk')
+        self._call('psh_topk', values.numel(), int(k), _ptr(values), _ptr(idx), _ptr(val), self._stream())
         return idx, val
 
     def bootstrap_means(self, data, num_reps: int, seed: int):
         """ [num_reps] means of len(data) draws with replacement each, on the device. """
         data = self.f64(data).reshape(-1)
         out = torch.empty(int(num_reps), dtype=torch.float64, device=self.device)
-        self._check(self.lib.psh_bootstrap_means(self._h, data.numel(), int(num_reps), _ptr(data), int(seed), _ptr(out),
-                                                 self._stream()), 'psh_bootstrap_means')
+        self._call('psh_bootstrap_means', data.numel(), int(num_reps), _ptr(data), int(seed), _ptr(out),
+                   self._stream())
         return out
 
 
