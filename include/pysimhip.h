@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 109
+#define PSH_VERSION 110
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -185,6 +185,13 @@ typedef struct psh_policy {
 #define PSH_F_SIMPLIFIED_DYN 2    /* QBallBalancerSim(simplified_dyn=True)                              */
 #define PSH_F_MAX_STEPS_INF 4     /* env.max_steps == inf inside step(): remaining_steps = 0, no time-out done
                                      (pysim/base.py:179,194); only meaningful for psh_step               */
+#define PSH_F_TRAJ_ENV_MAJOR 8    /* psh_rollout: trajectories one environment after the other, obs [N, T+1, O'],
+                                     act [N, T, A], rew [N, T]: every rollout is a contiguous block, as the
+                                     StepSequence of the reference holds it (sampling/step_sequence.py).  The
+                                     same numbers at other addresses, and slower to write: every lane stores
+                                     8-byte pieces into a block of its own (full-length OneMassOscillator
+                                     rollouts: 6 x the time and 5.7 x the bytes written of the default
+                                     layout; episodes of 70 steps: about equal) */
 
 /* per-env status bits */
 #define PSH_ST_NAN 1      /* NaN in observation, action or state: the reference raises ValueErr */
@@ -292,7 +299,8 @@ typedef struct psh_rollout_desc {
     int32_t* status;      /* [N]   PSH_ST_* bits */
     double* final_state;  /* [S, N] ld = N, state after the last executed step */
     double* obs;          /* [T+1, O', N] observations incl. the final one (O' = O, or the kept entries of
-                             OBS_PARTIAL); rows past length+1 untouched */
+                             OBS_PARTIAL); rows past length+1 untouched.  With PSH_F_TRAJ_ENV_MAJOR the three
+                             trajectory arrays are [N, T+1, O'], [N, T, A], [N, T] instead */
     double* act;          /* [T, A, N]   recorded actions (raw policy output; QBB: dead-zoned, see ACT_DELAY) */
     double* rew;          /* [T, N]      step rewards (final reward folded into the last step) */
     void* stream;

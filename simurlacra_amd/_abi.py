@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 109
+PSH_VERSION = 110
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -29,7 +29,7 @@ EXPL_NONE, EXPL_NORMAL, EXPL_UNIFORM = 0, 1, 2
 FEAT_IDS = dict(const=0, identity=1, sign=2, abs=3, squared=4, cubed=5, sig=6, bell=7, sin=8, cos=9, sinsin=10,
                 sincos=11, mult=12, rff=13, rbf=14)
 NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
-F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF = 1, 2, 4
+F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF, F_TRAJ_ENV_MAJOR = 1, 2, 4, 8
 ST_NAN, ST_FAILED, ST_TIMEOUT, ST_BERNOULLI, ST_BAD_INDEX = 1, 2, 4, 8, 16
 DISTR_CONST, DISTR_NORMAL, DISTR_UNIFORM, DISTR_BERNOULLI = range(4)
 WRAP_ACT_NORM, WRAP_ACT_DELAY, WRAP_ACT_NOISE, WRAP_OBS_NOISE, WRAP_OBS_NORM, WRAP_OBS_PARTIAL = range(1, 7)

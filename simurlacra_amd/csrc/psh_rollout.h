@@ -32,6 +32,9 @@ struct RolloutArgs {
     int img_doubles;       // FNN: doubles of one packed weight image in global memory (>= lds_doubles)
     const double* wfrag;   // FNN: packed weight image (device)
     double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
+    // element (step k, row r, env i) of a trajectory array is at k * sk + r * sr + i * si: time-major [T, rows, N] by default,
+    // one environment after the other [N, T, rows] with PSH_F_TRAJ_ENV_MAJOR
+    long obs_sk, obs_sr, obs_si, act_sk, act_sr, act_si, rew_sk, rew_si;
     unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
     const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
     const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
@@ -96,6 +99,11 @@ PSH_DEV double feat_apply(int id, double x) {
     default: return x;  // identity
     }
 }
+
+// One value of a trajectory.  A plain store: nontemporal stores (measured at 2^21 envs) change nothing for launches
+// whose waves write whole 512-byte rows and cost 25-40 % where refilled lanes write pieces of rows, which L2 no longer
+// merges.
+PSH_DEV void traj_store(double* p, double v) { *p = v; }
 
 // ------------------------------------------------------------------------------------------ one lane = one env
 // n standard normals for (seed, env, step, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p
@@ -291,7 +299,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
         if (a.obs) {
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
-                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
+                if (r < Oe) traj_store(a.obs + (k * a.obs_sk + r * a.obs_sr + i * a.obs_si), obs[r]);
         }
         if (nan) { st |= PSH_ST_NAN; live = false; }
     }
@@ -354,22 +362,22 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             rew = env_step<KIND>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+                for (int r = 0; r < E::A; ++r) traj_store(a.act + (k * a.act_sk + r * a.act_sr + i * a.act_si), act[r]);
                 // ActDelayWrapper queues the caller's array objects: without an array-creating wrapper the simulation
                 // wrote its dead zone (QBB) into the action recorded `delay` steps ago
                 if (rec_alias && k - delay >= 0) {
 #pragma unroll
-                    for (int r = 0; r < E::A; ++r) a.act[((long)(k - delay) * E::A + r) * a.n_envs + i] = inner[r];
+                    for (int r = 0; r < E::A; ++r) traj_store(a.act + ((k - delay) * a.act_sk + r * a.act_sr + i * a.act_si), inner[r]);
                 }
             }
         } else {
             rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) a.act[((long)k * E::A + r) * a.n_envs + i] = act[r];
+                for (int r = 0; r < E::A; ++r) traj_store(a.act + (k * a.act_sk + r * a.act_sr + i * a.act_si), act[r]);
             }
         }
-        if (a.rew) a.rew[(long)k * a.n_envs + i] = rew;
+        if (a.rew) traj_store(a.rew + (k * a.rew_sk + i * a.rew_si), rew);
         ret += rew;
         k += 1;
         if (st & PSH_ST_NAN) live = false;
@@ -390,7 +398,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             const int Oe = WRAP ? a.obs_dim : E::O;
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
-                if (r < Oe) a.obs[((long)k * Oe + r) * a.n_envs + i] = obs[r];
+                if (r < Oe) traj_store(a.obs + (k * a.obs_sk + r * a.obs_sr + i * a.obs_si), obs[r]);
         }
         a.ret[i] = ret;
         a.length[i] = k;
@@ -1065,6 +1073,18 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // wrappers, exploration noise and the stochastic reset live in the WRAP kernels
     const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
     a.obs_dim = Oe;
+    {
+        const long N = a.n_envs, T = a.max_steps;
+        if (a.flags & PSH_F_TRAJ_ENV_MAJOR) {
+            a.obs_sk = Oe; a.obs_sr = 1; a.obs_si = (T + 1) * Oe;
+            a.act_sk = E::A; a.act_sr = 1; a.act_si = T * E::A;
+            a.rew_sk = 1; a.rew_si = T;
+        } else {
+            a.obs_sk = Oe * N; a.obs_sr = N; a.obs_si = 1;
+            a.act_sk = E::A * N; a.act_sr = N; a.act_si = 1;
+            a.rew_sk = N; a.rew_si = 1;
+        }
+    }
     if (p.kind == PSH_POL_LINEAR) {
         if (p.n_feats < 1 || p.n_feats > PSH_MAX_FEATS) { set_err(c, "LinearPolicy needs 1..8 feature functions"); return PSH_ERR_ARG; }
         int F = 0;

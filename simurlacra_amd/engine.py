@@ -102,7 +102,8 @@ class Engine:
                 wrap=None, bernoulli_reset=0., final_state=True, out=None, static_scratch=False):
         """ N fused rollouts.  init_state [init_dim, N], domain_param [rows, M], params [n_policies, num_param]
         (device tensors, fp64).  Returns a dict of device tensors: ret [N], length [N], status [N], final_state [S, N]
-        and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N].  `wrap` (a WrapSpec) fuses environment
+        and, with record=True, obs [T+1, O, N], act [T, A, N], rew [T, N] (with F_TRAJ_ENV_MAJOR among the flags:
+        obs [N, T+1, O], act [N, T, A], rew [N, T], every rollout a contiguous block).  `wrap` (a WrapSpec) fuses environment
         wrappers into the step loop; with an ObsPartialWrapper in it O is the number of kept observations.
         policy_group = R > 0: population mode, env i runs params[i // R] (N = n_policies * R).
         static_scratch: issue the launch through psh_rollout_static, which takes its scratch from the library's static
@@ -123,9 +124,10 @@ class Engine:
             if final_state:
                 out['final_state'] = torch.empty((S, N), dtype=torch.float64, device=dev)
             if record:
-                out['obs'] = torch.full((T + 1, O_rec, N), float('nan'), dtype=torch.float64, device=dev)
-                out['act'] = torch.full((T, A, N), float('nan'), dtype=torch.float64, device=dev)
-                out['rew'] = torch.full((T, N), float('nan'), dtype=torch.float64, device=dev)
+                em = bool(flags & abi.F_TRAJ_ENV_MAJOR)
+                out['obs'] = torch.full((N, T + 1, O_rec) if em else (T + 1, O_rec, N), float('nan'), dtype=torch.float64, device=dev)
+                out['act'] = torch.full((N, T, A) if em else (T, A, N), float('nan'), dtype=torch.float64, device=dev)
+                out['rew'] = torch.full((N, T) if em else (T, N), float('nan'), dtype=torch.float64, device=dev)
         d = abi.PshRolloutDesc()
         d.env_kind, d.n_envs, d.max_steps, d.flags, d.dt = env_kind, N, T, flags, float(dt)
         d.init_state, d.init_dim, d.ld_init = _ptr(init_state), init_state.shape[0], N

@@ -229,6 +229,40 @@ def test_fused_delay_with_lane_refill(eng, orc):
     assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+@pytest.mark.parametrize('setup', ['bare', 'delay-alias', 'partial-obs', 'refill'])
+def test_env_major_trajectories_hold_the_same_numbers(eng, setup, policy):
+    """ PSH_F_TRAJ_ENV_MAJOR: obs [N, T+1, O'], act [N, T, A], rew [N, T] hold, bit for bit, what the time-major arrays
+    hold (same kernels, other addresses), entries past an episode's end stay untouched in both; incl. the ActDelayWrapper
+    case in which the simulation rewrites an action recorded `delay` steps earlier, a narrower observation, and a launch
+    with more envs than resident lanes. """
+    kind, n, T, wrap = abi.ENV_QBB, 300, 40, None
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    if setup == 'delay-alias':
+        wrap = cases.WrapSpec(ops=['act_delay'], act_delay=3)
+    elif setup == 'partial-obs':
+        wrap = cases.WrapSpec(ops=['obs_partial', 'act_norm'], obs_keep=[1, 0, 1, 1, 1, 0, 1, 1])
+    elif setup == 'refill':
+        kind, n, T = abi.ENV_BOB, 300000, 100
+        S, O, A, P, _ = abi.ENV_DIMS[kind]
+    kw = dict(scale=0.5 if kind == abi.ENV_QBB else 2.0, obs_dim=O if wrap is None else wrap.obs_dim(O))
+    if policy == 'fnn':
+        kw['hidden'] = (16, 16)
+    case = cases.make_case(kind, n, seed=77, policy=policy, **kw)
+    args = (kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'])
+    tm = eng.rollout(*args, record=True, wrap=wrap)
+    em = eng.rollout(*args, record=True, wrap=wrap, flags=abi.F_STOP_ON_DONE | abi.F_TRAJ_ENV_MAJOR)
+    Oe = kw['obs_dim']
+    assert tuple(em['obs'].shape) == (n, T + 1, Oe) and tuple(em['act'].shape) == (n, T, A) and tuple(em['rew'].shape) == (n, T)
+    for k in ('ret', 'length', 'status', 'final_state'):
+        assert bool((tm[k] == em[k]).all()), k
+    import torch
+    for k, perm in (('obs', (1, 2, 0)), ('act', (1, 2, 0)), ('rew', (1, 0))):
+        a, b = tm[k], em[k].permute(*perm)
+        assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), k
+    assert int(tm['length'].min()) < T or setup != 'refill'     # the refill case has episodes that end early
+
+
 @pytest.mark.parametrize('kind', cases.KINDS)
 def test_reset_step(eng, orc, kind):
     import torch

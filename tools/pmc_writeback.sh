@@ -1,14 +1,15 @@
 #!/bin/bash
 # HBM bytes of the trajectory-recording rollout kernels (tools/perf_writeback.py): WRITE_SIZE and FETCH_SIZE in counter
 # passes of their own, per launch of each k_rollout kernel, next to the algorithmic bytes the tool prints.
-# Usage: tools/pmc_writeback.sh <tag> [n_envs] [kinds]
+# Usage: tools/pmc_writeback.sh <tag> [n_envs] [kinds] [time_major|env_major]
 set -e
 out=gpurun_out/pmc_wb_$1
 n=${2:-2097152}
 kinds=${3:-omo,bob}
+mode=${4:-time_major}
 mkdir -p $out
-timeout -s KILL 170 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o w --output-format csv -- python3 tools/perf_writeback.py $n $kinds > $out/w.log 2>&1
-timeout -s KILL 170 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out -o f --output-format csv -- python3 tools/perf_writeback.py $n $kinds > $out/f.log 2>&1
+timeout -s KILL 170 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o w --output-format csv -- python3 tools/perf_writeback.py $n $kinds $mode > $out/w.log 2>&1
+timeout -s KILL 170 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out -o f --output-format csv -- python3 tools/perf_writeback.py $n $kinds $mode > $out/f.log 2>&1
 python3 - $out <<'PY'
 import csv, sys, collections
 out = sys.argv[1]
