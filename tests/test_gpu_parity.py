@@ -488,6 +488,34 @@ def test_full_size_launch_is_order_invariant_and_matches_the_oracle_on_a_sample(
     assert cases.rel_err(out['ret'].cpu().numpy()[sample], ref['ret']) <= 1e-6
 
 
+@pytest.mark.parametrize('kind', cases.KINDS, ids=[cases.KIND_NAMES[k] for k in cases.KINDS])
+def test_return_distributions_over_the_whole_horizon_match(eng, orc, kind):
+    """ Closed loops amplify rounding, so over hundreds of steps single rollouts of device and oracle may part; what the
+    algorithms consume is the distribution of returns.  10 000 rollouts per simulation over its whole horizon under a
+    64x64 tanh network with gains large enough for episodes to fail: the two samples of returns (same initial states
+    and parameters) must be indistinguishable -- two-sample Kolmogorov-Smirnov statistic, mean, quantiles -- and all but
+    a handful of rollouts must agree in length and, to 1e-6, in return. """
+    from scipy import stats
+    n, T = 10000, 600 if kind in (abi.ENV_QQ, abi.ENV_QQ_ST) else 500
+    case = cases.make_case(kind, n, seed=900 + kind, policy='fnn', hidden=(64, 64), scale=0.25)
+    args = (kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'])
+    ref = orc.rollout(*args)
+    out = eng.rollout(*args)
+    ret, length = out['ret'].cpu().numpy(), out['length'].cpu().numpy()
+    same_len = np.mean(length == ref['length'])
+    close = np.mean(np.abs(ret - ref['ret']) <= 1e-6*np.maximum(1., np.abs(ref['ret'])))
+    spread = max(np.std(ref['ret']), 1e-12)
+    ks = stats.ks_2samp(ret, ref['ret'], method='asymp').statistic
+    qs = [5, 25, 50, 75, 95]
+    dq = np.max(np.abs(np.percentile(ret, qs) - np.percentile(ref['ret'], qs)))/spread
+    dmean = abs(ret.mean() - ref['ret'].mean())/spread
+    msg = f'{cases.KIND_NAMES[kind]}: same length {same_len:.5f}, returns within 1e-6 {close:.5f}, KS {ks:.2e}, ' \
+          f'quantiles {dq:.2e} and mean {dmean:.2e} of the std; mean length {length.mean():.1f}'
+    print(msg)
+    assert same_len >= 0.999 and close >= 0.995, msg
+    assert ks <= 2e-3 and dq <= 2e-3 and dmean <= 1e-4, msg
+
+
 def test_large_launches_of_deeper_nets(eng, orc):
     """ Launch sizes at which the bare FNN kernel runs 12 waves per workgroup, with weight images of growing size (the
     staging areas of the extra waves must not cost the network its tanh table or its place in LDS): returns of a
