@@ -1,3 +1,6 @@
+#!/bin/bash
+# One GPU-box call: the GPU test suite, bench.py, the instruction counters of the LinearPolicy kernels and the per-simulation
+# kernel table (gpurun_out/r02_per_env_kernels.txt).  Usage: gpurun -- bash tools/run_gpu_checks.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
 tail -2 gpurun_out/gpu_tests.log
