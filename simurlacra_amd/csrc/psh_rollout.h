@@ -34,7 +34,8 @@ struct RolloutArgs {
     double* ret; int* length; int* status; double* final_state; double* obs; double* act; double* rew;
     // element (step k, row r, env i) of a trajectory array is at k * sk + r * sr + i * si: time-major [T, rows, N] by default,
     // one environment after the other [N, T, rows] with PSH_F_TRAJ_ENV_MAJOR
-    long obs_sk, obs_sr, obs_si, act_sk, act_sr, act_si, rew_sk, rew_si;
+    // (32-bit: an offset is three 32 x 32 -> 64-bit multiply-adds; the launch rejects arrays whose strides do not fit)
+    unsigned int obs_sk, obs_sr, obs_si, act_sk, act_sr, act_si, rew_sk, rew_si;
     unsigned int* queue;   // next unassigned env index (zeroed before the launch): lanes pull work from it
     const double* plate;   // QBB: plate angles from the IK prologue [2, N], or NULL (simplified dynamics)
     const double* tanh_tab;  // FNN: tanh table in global memory, copied to LDS by every workgroup
@@ -104,6 +105,10 @@ PSH_DEV double feat_apply(int id, double x) {
 // whose waves write whole 512-byte rows and cost 25-40 % where refilled lanes write pieces of rows, which L2 no longer
 // merges.
 PSH_DEV void traj_store(double* p, double v) { *p = v; }
+// offset (in elements) of (step k, row r, env i) in a trajectory array with the strides sk, sr, si
+PSH_DEV unsigned long traj_off(int k, int r, long i, unsigned int sk, unsigned int sr, unsigned int si) {
+    return (unsigned long)(unsigned int)k * sk + (unsigned long)(unsigned int)r * sr + (unsigned long)(unsigned int)i * si;
+}
 
 // ------------------------------------------------------------------------------------------ one lane = one env
 // n standard normals for (seed, env, step, stream): Box-Muller pairs, pair p from counter word 3 = stream + 16 p
@@ -299,7 +304,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
         if (a.obs) {
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
-                if (r < Oe) traj_store(a.obs + (k * a.obs_sk + r * a.obs_sr + i * a.obs_si), obs[r]);
+                if (r < Oe) traj_store(a.obs + traj_off(k, r, i, a.obs_sk, a.obs_sr, a.obs_si), obs[r]);
         }
         if (nan) { st |= PSH_ST_NAN; live = false; }
     }
@@ -362,22 +367,22 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             rew = env_step<KIND>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) traj_store(a.act + (k * a.act_sk + r * a.act_sr + i * a.act_si), act[r]);
+                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
                 // ActDelayWrapper queues the caller's array objects: without an array-creating wrapper the simulation
                 // wrote its dead zone (QBB) into the action recorded `delay` steps ago
                 if (rec_alias && k - delay >= 0) {
 #pragma unroll
-                    for (int r = 0; r < E::A; ++r) traj_store(a.act + ((k - delay) * a.act_sk + r * a.act_sr + i * a.act_si), inner[r]);
+                    for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k - delay, r, i, a.act_sk, a.act_sr, a.act_si), inner[r]);
                 }
             }
         } else {
             rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) traj_store(a.act + (k * a.act_sk + r * a.act_sr + i * a.act_si), act[r]);
+                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
             }
         }
-        if (a.rew) traj_store(a.rew + (k * a.rew_sk + i * a.rew_si), rew);
+        if (a.rew) traj_store(a.rew + traj_off(k, 0, i, a.rew_sk, 0u, a.rew_si), rew);
         ret += rew;
         k += 1;
         if (st & PSH_ST_NAN) live = false;
@@ -398,7 +403,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             const int Oe = WRAP ? a.obs_dim : E::O;
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
-                if (r < Oe) traj_store(a.obs + (k * a.obs_sk + r * a.obs_sr + i * a.obs_si), obs[r]);
+                if (r < Oe) traj_store(a.obs + traj_off(k, r, i, a.obs_sk, a.obs_sr, a.obs_si), obs[r]);
         }
         a.ret[i] = ret;
         a.length[i] = k;
@@ -1074,15 +1079,19 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
     a.obs_dim = Oe;
     {
-        const long N = a.n_envs, T = a.max_steps;
+        const unsigned long N = (unsigned long)a.n_envs, T = (unsigned long)a.max_steps, O_ = (unsigned long)Oe, A_ = E::A;
+        if ((d->obs || d->act || d->rew) && (O_ * N > 0xffffffffull || A_ * N > 0xffffffffull || (T + 1) * O_ > 0xffffffffull || T * A_ > 0xffffffffull)) {
+            set_err(c, "trajectory arrays whose strides exceed 2^32 elements are not supported");
+            return PSH_ERR_UNSUPPORTED;
+        }
         if (a.flags & PSH_F_TRAJ_ENV_MAJOR) {
-            a.obs_sk = Oe; a.obs_sr = 1; a.obs_si = (T + 1) * Oe;
-            a.act_sk = E::A; a.act_sr = 1; a.act_si = T * E::A;
-            a.rew_sk = 1; a.rew_si = T;
+            a.obs_sk = (unsigned)O_; a.obs_sr = 1; a.obs_si = (unsigned)((T + 1) * O_);
+            a.act_sk = (unsigned)A_; a.act_sr = 1; a.act_si = (unsigned)(T * A_);
+            a.rew_sk = 1; a.rew_si = (unsigned)T;
         } else {
-            a.obs_sk = Oe * N; a.obs_sr = N; a.obs_si = 1;
-            a.act_sk = E::A * N; a.act_sr = N; a.act_si = 1;
-            a.rew_sk = N; a.rew_si = 1;
+            a.obs_sk = (unsigned)(O_ * N); a.obs_sr = (unsigned)N; a.obs_si = 1;
+            a.act_sk = (unsigned)(A_ * N); a.act_sr = (unsigned)N; a.act_si = 1;
+            a.rew_sk = (unsigned)N; a.rew_si = 1;
         }
     }
     if (p.kind == PSH_POL_LINEAR) {
