@@ -42,6 +42,7 @@ struct RolloutArgs {
     int tanh_n;              // its length (fine or coarse table)
     int pop_tiles;           // FNN population mode: MFMA tiles (16 lanes each) per policy task: 1, 2 or 4
     int pop_groups;          // FNN population mode: groups of pop_tiles tiles a wave uses (the lanes beyond stay empty)
+    int wave_lanes;          // FNN, one policy: lanes of a wave that take environments (16, 32, 48 or 64; see launch_rollout)
 };
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
 
     Lane<KIND, WRAP> L;
     L.init();
+    if (!POP && lane >= a.wave_lanes) L.exhausted = true;  // a small launch is spread over more waves, fewer tiles each
 
     const int n_hidden = a.pol.n_hidden;
     int pol = 0;  // POP: policy of this lane's group of tiles
@@ -1184,7 +1186,21 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const long lanes12 = (long)c->num_cus * 768;
     // (and only if the four extra staging areas do not push the fine tanh table out of LDS)
     const bool fits12 = ((size_t)total + 12 * OP * 64 + TASK_DOUBLES + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
-    const int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
+    int BLOCK = (!per_env && !wrapped && fits12 && (long)d->n_envs >= 2 * lanes12) ? 768 : 512;
+    // A launch that does not fill two waves per SIMD is spread out: a wave-step costs its per-wave part plus one share
+    // per MFMA tile (16 lanes) in use, so 1 000 environments run three to four times faster as 63 waves of one tile on
+    // 63 CUs than as 16 full waves on 2.  Tiles per wave = what two waves per SIMD need to hold the launch; one wave per
+    // workgroup while there are more CUs than waves, then one per SIMD, then two.
+    long work_lanes = -1;
+    a.wave_lanes = 64;
+    const long tiles16 = ((long)d->n_envs + 15) / 16, simds = 4L * c->num_cus;
+    if (!per_env && tiles16 <= 8 * simds) {
+        const int tpw = (int)((tiles16 + 2 * simds - 1) / (2 * simds));   // 1..4
+        const long waves = (tiles16 + tpw - 1) / tpw;
+        BLOCK = waves <= c->num_cus ? 64 : (waves <= simds ? 256 : 512);
+        work_lanes = waves * 64;
+        a.wave_lanes = 16 * tpw;
+    }
     if (per_env && HP == 64 && p.n_hidden == 2 && all_tanh) {
         // population of two-hidden-layer tanh networks wider than 32: hidden-to-hidden weights in registers, one wave
         // per SIMD (see WREG at the kernel).  Up to 32 rollouts per policy: two policies per wave, 16 rollouts per task;
@@ -1258,8 +1274,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
     if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
 #define PSH_LAUNCH_FNN(HP_, FINE_, TANH_)                                                                                \
-    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false, TANH_>, BLOCK, lds_bytes, a, E::A, has_delay, st) \
-             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false, TANH_>, BLOCK, lds_bytes, a, E::A, false, st))
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, false, TANH_>, BLOCK, lds_bytes, a, E::A, has_delay, st, work_lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false, TANH_>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes))
     // the narrower kernels exist with the fine table only (on gfx950 their weight images always leave room for it)
     if (HP <= 32 && !fine) { set_err(c, "no LDS for the tanh table of this FNNPolicy"); return PSH_ERR_UNSUPPORTED; }
     if (HP == 16) return all_tanh ? PSH_LAUNCH_FNN(16, true, true) : PSH_LAUNCH_FNN(16, true, false);
