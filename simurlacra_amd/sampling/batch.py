@@ -402,24 +402,36 @@ class RolloutSummary:
 class RolloutBatch(Sequence):
     """ Result of a batched sampling call; behaves like the reference's List[StepSequence].  Items are built on
     access as views into the batched [T(+1), dim, N] arrays, so a million rollouts do not become a million Python
-    objects unless someone iterates over all of them. """
+    objects unless someone iterates over all of them.  Results come to the host one array at a time, on first use: the
+    per-rollout numbers (returns, lengths, status, domain parameters) as whole arrays, trajectories rollout by rollout
+    for the first BULK_AFTER items and as whole arrays from then on (a caller that looks at a few rollouts of a large
+    batch does not pay for gigabytes of device-to-host copies; one that iterates over all of them pays once). """
+    BULK_AFTER = 32
 
     def __init__(self, plan: EnvPlan, out: dict, dp, dp_index=None, env_spec=None, extra_dp=None, offset=0, count=None):
         self.plan, self._out = plan, out
         self._dp, self._dp_index = dp, dp_index
-        self._host = None
+        self._host = {}      # name -> numpy array; shared with the slices of this batch
         self._env_spec = env_spec if env_spec is not None else plan.env.spec
         self._extra = extra_dp
         self._offset = offset
         self._count = int(out['ret'].shape[0]) - offset if count is None else count
         self.dt = plan.sim.dt
 
-    def _h(self):
-        if self._host is None:
-            self._host = {k: v.detach().cpu().numpy() for k, v in self._out.items()}
-            self._host['dp'] = self._dp.detach().cpu().numpy()
-            self._host['dp_index'] = None if self._dp_index is None else self._dp_index.detach().cpu().numpy()
-        return self._host
+    def _h(self, key):
+        if key not in self._host:
+            v = self._dp if key == 'dp' else (self._dp_index if key == 'dp_index' else self._out[key])
+            self._host[key] = None if v is None else v.detach().cpu().numpy()
+        return self._host[key]
+
+    def _trajectory(self, g: int, L: int):
+        """ observations [L + 1, O], actions [L, A], rewards [L] of rollout g as host arrays """
+        n = self._host.get('_items', 0)
+        if 'obs' not in self._host and n < self.BULK_AFTER:
+            self._host['_items'] = n + 1
+            o = self._out
+            return (o['obs'][:L + 1, :, g].cpu().numpy(), o['act'][:L, :, g].cpu().numpy(), o['rew'][:L, g].cpu().numpy())
+        return self._h('obs')[:L + 1, :, g], self._h('act')[:L, :, g], self._h('rew')[:L, g]
 
     def __len__(self):
         return self._count
@@ -429,24 +441,24 @@ class RolloutBatch(Sequence):
         return self._out
 
     def undiscounted_returns(self) -> np.ndarray:
-        return self._h()['ret'][self._offset:self._offset + self._count]
+        return self._h('ret')[self._offset:self._offset + self._count]
 
     @property
     def lengths(self) -> np.ndarray:
-        return self._h()['length'][self._offset:self._offset + self._count]
+        return self._h('length')[self._offset:self._offset + self._count]
 
     @property
     def num_steps(self) -> int:
         return int(self.lengths.sum())
 
     def domain_param(self, i: int) -> dict:
-        h = self._h()
-        col = i if h['dp_index'] is None else int(h['dp_index'][i])
-        return self.plan.dp_dicts(h['dp'], [col], self._extra)[0]
+        idx = self._h('dp_index')
+        col = i if idx is None else int(idx[i])
+        return self.plan.dp_dicts(self._h('dp'), [col], self._extra)[0]
 
     def check(self):
         """ Raise as rollout() does when an observation, action or state became NaN in any lane. """
-        st = self._h()['status'][self._offset:self._offset + self._count]
+        st = self._h('status')[self._offset:self._offset + self._count]
         bad = np.flatnonzero(st & abi.ST_BAD_INDEX)
         if bad.size:
             raise ValueErr(msg=f'Rollout {int(bad[0])} of the batch names a domain-parameter column or a policy outside '
@@ -472,15 +484,15 @@ class RolloutBatch(Sequence):
             i += self._count
         if not 0 <= i < self._count:
             raise IndexError(i)
-        h = self._h()
         g = self._offset + i
-        L = int(h['length'][g])
+        L = int(self._h('length')[g])
         info = dict(env_spec=self._env_spec, domain_param=self.domain_param(g))
-        if 'obs' not in h or L == 0:
-            return RolloutSummary(h['ret'][g], L, info)
+        if 'obs' not in self._out or L == 0:
+            return RolloutSummary(self._h('ret')[g], L, info)
         done = np.zeros(L, dtype=bool)
         done[-1] = True
-        return StepSequence(observations=h['obs'][:L + 1, :, g], actions=h['act'][:L, :, g], rewards=h['rew'][:L, g],
+        obs, act, rew = self._trajectory(g, L)
+        return StepSequence(observations=obs, actions=act, rewards=rew,
                             env_infos=dict(t=np.arange(L)*self.dt), rollout_info=info, done=done, complete=True)
 
 

@@ -34,11 +34,36 @@ class ParameterSample(NamedTuple):
         return len(self.rollouts)
 
 
+class _LazySamples(Sequence):
+    """ The ParameterSample objects of a population, built on access: a CEM generation of 4 096 parameter sets reads the
+    mean returns and a few hundred elites, not 4 096 Python objects. """
+
+    def __init__(self, n: int, make):
+        self._n, self._make, self._cache = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[k] for k in range(*j.indices(self._n))]
+        j = int(j)
+        if j < 0:
+            j += self._n
+        if not 0 <= j < self._n:
+            raise IndexError(j)
+        if j not in self._cache:
+            self._cache[j] = self._make(j)
+        return self._cache[j]
+
+
 class ParameterSamplingResult(Sequence):
-    def __init__(self, samples: List[ParameterSample], mean_returns: np.ndarray = None, mean_returns_device=None):
+    def __init__(self, samples: Sequence, mean_returns: np.ndarray = None, mean_returns_device=None,
+                 param_sets: to.Tensor = None, num_rollouts: int = None):
         self._samples = samples
         self._mean_returns = mean_returns
         self._means_dev = mean_returns_device     # the same means, still on the GPU (all parameter sets, every rank)
+        self._param_sets, self._num_rollouts = param_sets, num_rollouts
 
     def __getitem__(self, idx):
         res = self._samples[idx]
@@ -52,6 +77,8 @@ class ParameterSamplingResult(Sequence):
 
     @property
     def parameters(self) -> to.Tensor:
+        if self._param_sets is not None:
+            return self._param_sets
         return to.stack([s.params for s in self._samples])
 
     @property
@@ -82,6 +109,8 @@ class ParameterSamplingResult(Sequence):
 
     @property
     def num_rollouts(self) -> int:
+        if self._num_rollouts is not None:
+            return self._num_rollouts
         return int(np.sum([s.num_rollouts for s in self._samples]))
 
 
@@ -134,8 +163,8 @@ class ParameterExplorationSampler:
         means = means_dev.cpu().numpy()
         if ws == 1:
             batch.check()
-            samples = [ParameterSample(params=param_sets[j], rollouts=batch.slice(j*R, R)) for j in range(pop)]
-            return ParameterSamplingResult(samples, means, means_dev)
+            samples = _LazySamples(pop, lambda j: ParameterSample(params=param_sets[j], rollouts=batch.slice(j*R, R)))
+            return ParameterSamplingResult(samples, means, means_dev, param_sets, pop*R)
         # every rank gets the returns, lengths and status words of ALL parameter sets ([pop, R] each; trajectories
         # stay where they were produced), so num_rollouts, len(rollout) and slicing of the result agree on all ranks
         ret = D.all_gather_rows(out['ret'].view(my, R), pop).cpu().numpy()
@@ -148,11 +177,10 @@ class ParameterExplorationSampler:
 
         def dp_of(r):
             return plan.dp_dicts(dp_host, [r])[0]
-        samples = []
-        for j in range(pop):
+        def make(j):
             if p0 <= j < p1:
                 ros = batch.slice((j - p0)*R, R)
             else:
                 ros = SummaryRollouts(ret[j], length[j], dp_of, batch._env_spec)
-            samples.append(ParameterSample(params=param_sets[j], rollouts=ros))
-        return ParameterSamplingResult(samples, means, means_dev)
+            return ParameterSample(params=param_sets[j], rollouts=ros)
+        return ParameterSamplingResult(_LazySamples(pop, make), means, means_dev, param_sets, pop*R)
