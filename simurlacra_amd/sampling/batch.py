@@ -454,6 +454,10 @@ class RolloutBatch(Sequence):
     def domain_param(self, i: int) -> dict:
         idx = self._h('dp_index')
         col = i if idx is None else int(idx[i])
+        n = self._host.get('_dp_items', 0)
+        if 'dp' not in self._host and n < self.BULK_AFTER:   # one column of a table that may hold a million of them
+            self._host['_dp_items'] = n + 1
+            return self.plan.dp_dicts(self._dp[:, col:col + 1].cpu().numpy(), [0], self._extra)[0]
         return self.plan.dp_dicts(self._h('dp'), [col], self._extra)[0]
 
     def check(self):
