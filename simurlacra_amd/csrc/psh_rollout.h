@@ -1207,9 +1207,16 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         // more: the whole wave on one policy, 64 rollouts per task.
         const int block_l1 = HT * KS * 64;
         const bool two = p.policy_group <= 32;
-        const int sets = two ? 2 : 1, task_lanes = two ? 16 : 64;
+        const int sets = two ? 2 : 1;
+        // one policy per wave: a task takes 64 lanes, or 32 / 16 as long as that still leaves every task a SIMD of its own
+        // (512 policies x 64 rollouts: 1 024 waves of two tiles instead of 512 waves of four on half of the chip)
+        int task_lanes = two ? 16 : 64;
+        if (!two) {
+            const long simds = 4L * c->num_cus;
+            while (task_lanes > 16 && (long)p.n_policies * ((p.policy_group + task_lanes / 2 - 1) / (task_lanes / 2)) <= simds) task_lanes /= 2;
+        }
         a.lds_doubles = total - block_l1;
-        a.pop_tiles = two ? 1 : 4;
+        a.pop_tiles = task_lanes / 16;
         a.pop_groups = two ? 2 : 1;
         a.tanh_tab = c->tanh_tab;
         a.tanh_n = PSH_TANH8_N;
