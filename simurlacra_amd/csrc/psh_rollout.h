@@ -600,6 +600,32 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_li
 // the widest, deepest networks leave no room for it and run with the coarse one.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// x(lane) + x(lane ^ 16) + x(lane ^ 32) + x(lane ^ 48) in every lane, in the order (x + x^16) + (that of lane ^ 32):
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second, so swapping a
+// value with a copy of itself leaves [r0 r0 r2 r2] and [r1 r1 r3 r3]; v_permlane32_swap does the same with the halves.
+PSH_DEV double sum_over_lane_groups(double x) {
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(s); hi = (unsigned)__double2hiint(s);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// all N values in registers at this point of the program (so that the loads that produce them are all in flight before
+// the first of them is used)
+template <int N> PSH_DEV void hold_together(double* v) {
+    static_assert(N == 4 || N == 8 || N == 16, "one statement per size");
+    if constexpr (N == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    if constexpr (N == 8)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    if constexpr (N == 16)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
 // y[0..N) are the pre-activations this lane holds for ONE environment; all of them feed every unit of the next
 // layer, so a NaN in any of them has to end up in the action.  The table tanh loses NaNs (its clamp works on
 // the high word), so the largest |y| high word of the layer is tracked (one 32-bit max per element) and a NaN is put
@@ -731,6 +757,13 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
         for (int g = 0; g < NSET; ++g)
 #pragma unroll
             for (int f = 0; f < HT * KS; ++f) wreg[g][f] = 0.;
+    }
+    // one policy: which hidden layers may run the activation without clamp (read once; per tile it would be an LDS round
+    // trip in front of every layer's activations)
+    int bounded_layers = 0;
+    if constexpr (!POP) {
+        for (int l = 1; l < n_hidden; ++l) bounded_layers |= (w_lds[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT ? 1 : 0) << l;
+        bounded_layers = __builtin_amdgcn_readfirstlane(bounded_layers);
     }
     for (;;) {
         if constexpr (POP) {
@@ -880,6 +913,14 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
 #pragma unroll
                     for (int s = 0; s < KS; ++s)
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(t * KS + s) * 64 + lane], x[s], acc, 0, 0, 0);
+                    // the fragment reads run one pair of MFMAs ahead (by itself the scheduler issues each read right before
+                    // its MFMAs and waits for it: no loss with three waves per SIMD, a bubble per pair for a wave alone)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int s = 0; s < KS; s += 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
@@ -887,21 +928,27 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                 // behind a tanh layer the inputs lie in [-1, 1]: if the weights of this layer keep every pre-activation
                 // below the table's end (row sums of |W| plus |b|, computed by k_fnn_bounds), the clamp and the NaN
                 // bookkeeping of the activation are not needed
-                if (TANH && FINE && wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT)
+                if (TANH && FINE && (POP ? wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0))
                     nl_apply_all<KS, FINE, true>((int)PSH_NL_TANH, y, tanh_tab);
                 else
                     nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
                 off += HT * KS * 64 + HP;
             }
-            // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added
+            // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added.  The
+            // weights are all requested before the first product (left alone, the compiler reuses one register pair and
+            // waits for every LDS read in turn), and the two exchange steps run on the vector ALU (row swaps) instead of
+            // going through LDS: both are latency a wave alone on its SIMD cannot hide.
             const double* wo = wimg + off;
 #pragma unroll
             for (int r = 0; r < E::A; ++r) {
+                double wv[KS];
+#pragma unroll
+                for (int m = 0; m < KS; ++m) wv[m] = wo[r * HP + (m >> 2) * 16 + (m & 3) * 4 + q];
+                hold_together<KS>(wv);
                 double p = 0.;
 #pragma unroll
-                for (int m = 0; m < KS; ++m) p += wo[r * HP + (m >> 2) * 16 + (m & 3) * 4 + q] * y[m];
-                p += __shfl_xor(p, 16);
-                p += __shfl_xor(p, 32);
+                for (int m = 0; m < KS; ++m) p += wv[m] * y[m];
+                p = sum_over_lane_groups(p);
                 p += wo[E::A * HP + r];
                 if (q == tile) act[r] = p;
             }
