@@ -165,7 +165,11 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             if (chunk_next == chunk_end) {
                 // one draw covers every lane that is waiting, in whole lines (the first fill of a wave takes 64 at once:
                 // eight draws each would queue eight times as many atomics of all waves on one address)
-                const unsigned int size = ((unsigned int)__popcll(m) + QUEUE_CHUNK - 1) / QUEUE_CHUNK * QUEUE_CHUNK;
+                // (BATCH > 1, the LinearPolicy kernels with their short steps: at least 4 BATCH envs per draw, handed out over
+                // the wave's next exchanges.  With episodes of 70 steps a million envs drawn 8 at a time are 131 072 atomics
+                // on one address, which L2 serialises at about 10 ns each: more than the rollouts themselves take)
+                unsigned int size = ((unsigned int)__popcll(m) + QUEUE_CHUNK - 1) / QUEUE_CHUNK * QUEUE_CHUNK;
+                if (BATCH > 1 && size < 4u * BATCH) size = 4u * BATCH;
                 unsigned int base = 0;
                 if ((threadIdx.x & 63) == 0) base = atomicAdd(a.queue, size);
                 base = __builtin_amdgcn_readfirstlane(base);
