@@ -41,15 +41,6 @@ PSH_MATH double psh_div_by(double n, double d, double r) {
     return fma(fma(-d, q, n), r, q);
 }
 
-// a * b + c for a literal c of a Horner chain, with c in scalar registers.  Left to itself the compiler picks the
-// accumulating two-operand form (v_fmac_f64), which needs c in the destination first: two v_mov_b32 per coefficient on the
-// vector ALU, whose issue slots are what the LinearPolicy step loops run out of; the scalar unit has room.
-PSH_MATH double psh_fma_k(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-
 // exp(x) - 1 split as (k, q): exp(x) = 2^k * (1 + q), |q| <= 0.42.  Shared by exp, tanh and sigmoid.
 PSH_MATH double psh_exp_poly(double x, int& k) {
     const double kd = rint(x * 1.4426950408889634074);
@@ -58,16 +49,16 @@ PSH_MATH double psh_exp_poly(double x, int& k) {
     r = fma(-kd, 1.90821492927058770002e-10, r);          // ln2 low part
     // q = r + r^2/2! + ... + r^13/13!
     double p = 1.6059043836821613e-10;                     // 1/13!
-    p = psh_fma_k(p, r, 2.08767569878681e-09);                   // 1/12!
-    p = psh_fma_k(p, r, 2.505210838544172e-08);                  // 1/11!
-    p = psh_fma_k(p, r, 2.755731922398589e-07);                  // 1/10!
-    p = psh_fma_k(p, r, 2.7557319223985893e-06);                 // 1/9!
-    p = psh_fma_k(p, r, 2.48015873015873e-05);                   // 1/8!
-    p = psh_fma_k(p, r, 1.984126984126984e-04);                  // 1/7!
-    p = psh_fma_k(p, r, 1.388888888888889e-03);                  // 1/6!
-    p = psh_fma_k(p, r, 8.333333333333333e-03);                  // 1/5!
-    p = psh_fma_k(p, r, 4.1666666666666664e-02);                 // 1/4!
-    p = psh_fma_k(p, r, 1.6666666666666666e-01);                 // 1/3!
+    p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                  // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                  // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                 // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                   // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                  // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);                  // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                  // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                 // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     return p * r;
@@ -198,19 +189,19 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
     const double z = r * r;
     // sin kernel on [-pi/4, pi/4]
     double ps = 1.58969099521155010221e-10;
-    ps = psh_fma_k(ps, z, -2.50507602534068634195e-08);
-    ps = psh_fma_k(ps, z, 2.75573137070700676789e-06);
-    ps = psh_fma_k(ps, z, -1.98412698298579493134e-04);
-    ps = psh_fma_k(ps, z, 8.33333333332248946124e-03);
-    ps = psh_fma_k(ps, z, -1.66666666666666324348e-01);
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
     const double sn = fma(ps * z, r, r);
     // cos kernel on [-pi/4, pi/4]
     double pc = -1.13596475577881948265e-11;
-    pc = psh_fma_k(pc, z, 2.08757232129817482790e-09);
-    pc = psh_fma_k(pc, z, -2.75573143513906633035e-07);
-    pc = psh_fma_k(pc, z, 2.48015872894767294178e-05);
-    pc = psh_fma_k(pc, z, -1.38888888888741095749e-03);
-    pc = psh_fma_k(pc, z, 4.16666666666666019037e-02);
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
     const double cs = fma(pc * z, z, fma(-0.5, z, 1.0));
     const double ss = (n & 1) ? cs : sn;
     const double cc = (n & 1) ? sn : cs;
