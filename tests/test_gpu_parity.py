@@ -548,6 +548,52 @@ def test_ragged_and_empty_batches(eng, orc):
     assert out['ret'].numel() == 0
 
 
+@pytest.mark.parametrize('n', [15, 17, 4095, 4097, 16385, 32769, 65537, 98305, 131073])
+def test_small_and_medium_fnn_launches_at_the_edges_of_their_layouts(eng, orc, n):
+    """ FNN launches below two full waves per SIMD are spread over more waves with fewer MFMA tiles each (1-4 tiles per wave,
+    1, 4 or 8 waves per workgroup): batch sizes next to every switch of that layout, bare and behind a wrapper chain with
+    an action delay (whose ring buffers are indexed by the resident lane), against the oracle. """
+    kind, T = abi.ENV_QCP_ST, 12
+    case = cases.make_case(kind, n, seed=n, policy='fnn', hidden=(64, 64), scale=0.3)
+    args = (kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'])
+    for wrap in (None, cases.WrapSpec(ops=['act_delay', 'act_norm'], act_delay=2)):
+        ref = orc.rollout(*args, wrap=wrap)
+        out = eng.rollout(*args, wrap=wrap)
+        np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+        np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+        assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
+        assert cases.rel_err(out['final_state'].cpu().numpy(), ref['final_state']) <= TOL
+
+
+def test_one_engine_from_two_threads(eng, orc):
+    """ Rollouts issued from two host threads through one engine (one context): the calls are serialised on the host and
+    ordered on the device, so each gets the results of a call made alone. """
+    import threading
+    kind, T = abi.ENV_QQ, 40
+    jobs = [cases.make_case(kind, 3000 + 500*j, seed=50 + j, policy='fnn' if j % 2 else 'linear', scale=0.3) for j in range(4)]
+    alone = [eng.rollout(kind, c['dt'], T, c['task_c'], c['ps'], c['params'], c['init'], c['dp']) for c in jobs]
+    got = [None]*len(jobs)
+
+    def work(j0):
+        import torch
+        stream = torch.cuda.Stream(device=eng.device)
+        with torch.cuda.stream(stream):
+            for rep in range(5):
+                for j in range(j0, len(jobs), 2):
+                    c = jobs[j]
+                    got[j] = eng.rollout(kind, c['dt'], T, c['task_c'], c['ps'], c['params'], c['init'], c['dp'])
+            stream.synchronize()
+    threads = [threading.Thread(target=work, args=(j0,)) for j0 in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    import torch
+    for a, g in zip(alone, got):
+        for key in ('ret', 'length', 'status', 'final_state'):
+            assert torch.equal(a[key], g[key]), key
+
+
 def test_stop_on_done_false_and_long_horizon_failures(eng, orc):
     """ rollout(stop_on_done=False): the env keeps stepping after done, the final reward is given once. """
     kind = abi.ENV_OMO
