@@ -709,7 +709,7 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // (more than 32 rollouts per policy); WREG = 2: tiles 0 and 1 of the wave run one policy each, two register sets, the
 // other 32 lanes stay empty -- eight policies resident per CU, and the environment step of a wave serves two of them.
 constexpr int NSET_OF(int wreg) { return wreg == 2 ? 2 : 1; }
-template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0>
+template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
 __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     static_assert(!WREG || (POP && TANH && FINE && HP == 64), "WREG is the population kernel of the 64-wide tanh networks");
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
     stage_task(a, task_lds);
     __syncthreads();
 
-    Lane<KIND, WRAP> L;
+    Lane<KIND, WRAP, FIXT> L;   // FIXT: the simulation's default task shape compiled in (see k_rollout_linear)
     L.init();
     if (!POP && lane >= a.wave_lanes) L.exhausted = true;  // a small launch is spread over more waves, fewer tiles each
 
@@ -1336,6 +1336,14 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, false, TANH_>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes))
     // the narrower kernels exist with the fine table only (on gfx950 their weight images always leave room for it)
     if (HP <= 32 && !fine) { set_err(c, "no LDS for the tanh table of this FNNPolicy"); return PSH_ERR_UNSUPPORTED; }
+    // the usual case has kernels of its own: bare simulation with its default task shape, all-tanh network, fine table
+    if (!wrapped && all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
+#define PSH_LAUNCH_FNN_FIXT(HP_) launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes)
+        if (HP == 16) return PSH_LAUNCH_FNN_FIXT(16);
+        if (HP == 32) return PSH_LAUNCH_FNN_FIXT(32);
+        return PSH_LAUNCH_FNN_FIXT(64);
+#undef PSH_LAUNCH_FNN_FIXT
+    }
     if (HP == 16) return all_tanh ? PSH_LAUNCH_FNN(16, true, true) : PSH_LAUNCH_FNN(16, true, false);
     if (HP == 32) return all_tanh ? PSH_LAUNCH_FNN(32, true, true) : PSH_LAUNCH_FNN(32, true, false);
     if (fine) return all_tanh ? PSH_LAUNCH_FNN(64, true, true) : PSH_LAUNCH_FNN(64, true, false);
