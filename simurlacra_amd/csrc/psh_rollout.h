@@ -1275,9 +1275,10 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         if (lds_w <= c->lds_per_block) {
             const long tasks = (long)p.n_policies * ((p.policy_group + task_lanes - 1) / task_lanes);
             const long lanes = (tasks + sets - 1) / sets * 64;   // a wave takes `sets` tasks at a time
-#define PSH_LAUNCH_WREG(WRAP_, SETS_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
-            if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2) : PSH_LAUNCH_WREG(false, 2);
-            return wrapped ? PSH_LAUNCH_WREG(true, 1) : PSH_LAUNCH_WREG(false, 1);
+#define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
+            const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
+            if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2, false) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
+            return wrapped ? PSH_LAUNCH_WREG(true, 1, false) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
 #undef PSH_LAUNCH_WREG
         }
         a.lds_doubles = total;
@@ -1318,6 +1319,14 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
 #define PSH_LAUNCH_POP(HP_, FINE_, TANH_)                                                                                \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
+        // (the usual case again with kernels of its own: bare simulation, default task shape, all-tanh, fine table)
+        if (!wrapped && all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
+#define PSH_LAUNCH_POP_FIXT(HP_) launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true, true, 0, true>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes)
+            if (HP == 16) return PSH_LAUNCH_POP_FIXT(16);
+            if (HP == 32) return PSH_LAUNCH_POP_FIXT(32);
+            return PSH_LAUNCH_POP_FIXT(64);
+#undef PSH_LAUNCH_POP_FIXT
+        }
         if (HP == 16) return all_tanh ? PSH_LAUNCH_POP(16, true, true) : PSH_LAUNCH_POP(16, true, false);
         if (HP == 32 && fine) return all_tanh ? PSH_LAUNCH_POP(32, true, true) : PSH_LAUNCH_POP(32, true, false);
         if (HP == 32) return all_tanh ? PSH_LAUNCH_POP(32, false, true) : PSH_LAUNCH_POP(32, false, false);
