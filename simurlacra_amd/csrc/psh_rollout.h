@@ -618,6 +618,14 @@ PSH_DEV double sum_over_lane_groups(double x) {
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
+// x of the lane N places further down in this lane's row of 16 (cyclically): two v_mov_b32 with a row_ror modifier
+template <int N> PSH_DEV double rotate_in_row(double x) {
+    static_assert(N > 0 && N < 16, "row_ror:1 .. row_ror:15");
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x120 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x120 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // all N values in registers at this point of the program (so that the loads that produce them are all in flight before
 // the first of them is used)
 template <int N> PSH_DEV void hold_together(double* v) {
@@ -708,7 +716,11 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // its policies (256 threads per workgroup leave a wave all 512 registers).  WREG = 1: the whole wave runs one policy
 // (more than 32 rollouts per policy); WREG = 2: tiles 0 and 1 of the wave run one policy each, two register sets, the
 // other 32 lanes stay empty -- eight policies resident per CU, and the environment step of a wave serves two of them.
-constexpr int NSET_OF(int wreg) { return wreg == 2 ? 2 : 1; }
+// WREG = 3: as WREG = 2 for up to 8 rollouts per policy, where half of the 16 columns of a 16x16x4 tile would be empty.
+// The layers run on v_mfma_f64_4x4x4_4b_f64 instead: four independent 4 x 4 x 4 blocks per instruction at the same
+// rate per multiply-add (16 cycles), here four groups of 4 hidden units against the same 4 rollouts, so a layer costs
+// two column groups of 4 instead of one of 16 -- half the MFMA time and half the activations.
+constexpr int NSET_OF(int wreg) { return wreg >= 2 ? 2 : 1; }
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
 __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
@@ -754,13 +766,21 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
     const int n_hidden = a.pol.n_hidden;
     int pol = 0;  // POP: policy of this lane's group of tiles
     // WREG: fragment (t, s) of the hidden-to-hidden weights of this wave's policy / of the policies of its tiles 0 and 1
-    constexpr int NSET = WREG == 2 ? 2 : 1;
+    constexpr int NSET = NSET_OF(WREG);
     double wreg[NSET][WREG ? HT * KS : 1];
     if constexpr (WREG != 0) {
 #pragma unroll
         for (int g = 0; g < NSET; ++g)
 #pragma unroll
             for (int f = 0; f < HT * KS; ++f) wreg[g][f] = 0.;
+    }
+    // WREG = 3: the 4-lane block whose value a rotation by 4 rot lanes within the row of 16 delivers to this lane
+    int b_from[4] = {0, 0, 0, 0};
+    if constexpr (WREG == 3) {
+        b_from[0] = (lane >> 2) & 3;
+        b_from[1] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 4, 0xf, 0xf, false) >> 2) & 3;
+        b_from[2] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 8, 0xf, 0xf, false) >> 2) & 3;
+        b_from[3] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 12, 0xf, 0xf, false) >> 2) & 3;
     }
     // one policy: which hidden layers may run the activation without clamp (read once; per tile it would be an LDS round
     // trip in front of every layer's activations)
@@ -784,7 +804,20 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                         constexpr int OFF1 = HT * K0 * 64 + REM * HP + HP, BLOCK = HT * KS * 64;
                         for (int j = lane; j < OFF1; j += 64) dst[j] = src[j];
                         for (int j = OFF1 + lane; j < a.lds_doubles; j += 64) dst[j] = src[j + BLOCK];
-                        if (NSET == 1 || first < 16) {
+                        // WREG = 3: register (rs, rp, rot) holds the lane's value of fragment (rs, 4 rp + block the rotation
+                        // `rot` of the activations reads from), see run_narrow.  One base per rotation, constant offsets behind it.
+                        if constexpr (WREG == 3) {
+                            const double* base[4];
+#pragma unroll
+                            for (int rot = 0; rot < 4; ++rot) base[rot] = src + OFF1 + b_from[rot] * 64 + lane;
+                            if (first < 16) {
+#pragma unroll
+                                for (int f = 0; f < HT * KS; ++f) wreg[0][f] = base[f & 3][((f >> 4) * KS + 4 * ((f >> 2) & 3)) * 64];
+                            } else {
+#pragma unroll
+                                for (int f = 0; f < HT * KS; ++f) wreg[NSET - 1][f] = base[f & 3][((f >> 4) * KS + 4 * ((f >> 2) & 3)) * 64];
+                            }
+                        } else if (NSET == 1 || first < 16) {
 #pragma unroll
                             for (int f = 0; f < HT * KS; ++f) wreg[0][f] = src[OFF1 + f * 64 + lane];
                         } else {
@@ -957,7 +990,124 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                 if (q == tile) act[r] = p;
             }
         };
-        if constexpr (WREG == 2) {   // two tiles, each with the register set of its own policy
+        // WREG = 3: the policy forward of the up to 8 environments in the first 8 lanes of tile p, on 4x4x4 MFMAs.
+        // Lane (h, b, l) = 16 h + 4 b + l supplies A_b[i = l][k = h] and B_b[k = h][j = l] of block b and receives
+        // D_b[i = h][j = l].  Block b takes the hidden units 16 rs + 4 b + (0..3) of row step rs, all blocks the same 4
+        // environments 16 p + 4 g + (0..3) of column group g: the lane holds unit 16 rs + 4 b + h of environment 4 g + l,
+        // y[g][rs].  As the B operand of the next layer block b needs the units 4 ks + h of k-step ks: its own for
+        // ks = 4 rp + b, those of the other blocks by rotating the row of 16 lanes by 4, 8 and 12 -- every block goes
+        // through the 16 k-steps in an order of its own, which its weight registers follow (frag_of above).
+        auto run_narrow = [&](const int p, const double* wr) {
+            if constexpr (WREG == 3) {
+                if (((live_mask >> (16 * p)) & 0xFFFFull) == 0) return;
+                constexpr int NG = 2;
+                const double* const wimg = w_lds + p * a.lds_doubles;
+                const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
+                const int unit = 4 * b + h;          // + 16 rs
+                const int env_lane = 16 * p + l;     // + 4 g
+                double y[NG][HT];
+                {
+                    double xin[K0 > 0 ? K0 : 1][NG], xr[REM > 0 ? REM : 1][NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                        for (int s = 0; s < K0; ++s) xin[s][g] = stage[(4 * s + h) * 64 + env_lane + 4 * g];
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) xr[j][g] = stage[(4 * K0 + j) * 64 + env_lane + 4 * g];
+                    }
+                    const double* wl = wimg;
+                    const double* wrem = wimg + HT * K0 * 64;
+                    const double* bl = wrem + REM * HP;
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) {
+                        const double bias = bl[16 * rs + unit];
+                        double wj[REM > 0 ? REM : 1], wa[K0 > 0 ? K0 : 1];
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) wj[j] = wrem[j * HP + 16 * rs + unit];
+#pragma unroll
+                        for (int s = 0; s < K0; ++s) wa[s] = wl[(rs * K0 + s) * 64 + lane];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            double acc = bias;
+#pragma unroll
+                            for (int j = 0; j < REM; ++j) acc = fma(wj[j], xr[j][g], acc);
+#pragma unroll
+                            for (int s = 0; s < K0; ++s) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s], xin[s][g], acc, 0, 0, 0);
+                            y[g][rs] = acc;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                }
+                int off = HT * K0 * 64 + REM * HP + HP;
+                {
+                    const double* bl = wimg + off;
+                    double acc[HT][NG];
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) {
+                        const double bias = bl[16 * rs + unit];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[rs][g] = bias;
+                    }
+#pragma unroll
+                    for (int rp = 0; rp < HT; ++rp) {
+#pragma unroll
+                        for (int rot = 0; rot < 4; ++rot) {
+                            double xb[NG];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                if (rot == 0) xb[g] = y[g][rp];
+                                if (rot == 1) xb[g] = rotate_in_row<4>(y[g][rp]);
+                                if (rot == 2) xb[g] = rotate_in_row<8>(y[g][rp]);
+                                if (rot == 3) xb[g] = rotate_in_row<12>(y[g][rp]);
+                            }
+#pragma unroll
+                            for (int rs = 0; rs < HT; ++rs)
+#pragma unroll
+                                for (int g = 0; g < NG; ++g)
+                                    acc[rs][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr[(rs * 4 + rp) * 4 + rot], xb[g], acc[rs][g], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int rs = 0; rs < HT; ++rs) y[g][rs] = acc[rs][g];
+                    if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, true>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    }
+                    off += HP;
+                }
+                // output layer: the lane's 4 units per environment, then the sum over the 16 lanes (b, h) with the same l
+                const double* wo = wimg + off;
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) {
+                    double wv[HT];
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) wv[rs] = wo[r * HP + 16 * rs + unit];
+                    hold_together<HT>(wv);
+                    const double bo = wo[E::A * HP + r];
+                    double pg[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        double s = 0.;
+#pragma unroll
+                        for (int rs = 0; rs < HT; ++rs) s += wv[rs] * y[g][rs];
+                        s += rotate_in_row<4>(s);
+                        s += rotate_in_row<8>(s);
+                        pg[g] = sum_over_lane_groups(s) + bo;
+                    }
+                    if (h == p && b < NG) act[r] = b == 0 ? pg[0] : pg[NG - 1];
+                }
+            }
+        };
+        if constexpr (WREG == 3) {   // two policies of up to 8 rollouts, each with its own register set
+            run_narrow(0, wreg[0]);
+            run_narrow(1, wreg[1]);
+        } else if constexpr (WREG == 2) {   // two tiles, each with the register set of its own policy
             run_tile(0, wreg[0]);
             run_tile(1, wreg[1]);
         } else {
@@ -1277,6 +1427,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
             const long lanes = (tasks + sets - 1) / sets * 64;   // a wave takes `sets` tasks at a time
 #define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
             const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
+            // (up to 8 rollouts per policy: the layers on 4x4x4 MFMAs, two column groups of 4 instead of a tile of 16)
+            if (two && p.policy_group <= 8) return wrapped ? PSH_LAUNCH_WREG(true, 3, false) : (fixt ? PSH_LAUNCH_WREG(false, 3, true) : PSH_LAUNCH_WREG(false, 3, false));
             if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2, false) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
             return wrapped ? PSH_LAUNCH_WREG(true, 1, false) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
 #undef PSH_LAUNCH_WREG

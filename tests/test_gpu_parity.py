@@ -457,6 +457,43 @@ def test_large_fnn_population(eng, orc, kind, pop, R, hidden):
     assert cases.rel_err(out['ret'].cpu().numpy(), ref['ret']) <= TOL
 
 
+@pytest.mark.parametrize('kind,R,hidden', [(abi.ENV_QQ, 8, (64, 64)), (abi.ENV_QQ, 5, (48, 40)), (abi.ENV_QBB, 8, (64, 64)),
+                                           (abi.ENV_QBB, 3, (64, 64)), (abi.ENV_OMO, 1, (64, 64)), (abi.ENV_BOB, 7, (40, 64)),
+                                           (abi.ENV_QCP_SU, 4, (64, 64)), (abi.ENV_PEND, 8, (33, 17))])
+def test_populations_of_up_to_8_rollouts_per_policy(eng, orc, kind, R, hidden):
+    """ Two-hidden-layer tanh networks wider than 32 with at most 8 rollouts per policy run their layers in column groups
+    of 4 rollouts (4x4x4 MFMAs) instead of tiles of 16: every observation size (whole groups of 4 inputs and left-over
+    inputs), full and partly filled column groups, padded layer widths, more policies than fit the chip at once, recorded
+    trajectories; then a task that is not the simulation's default one, and weights large enough for the clamping tanh. """
+    import dataclasses
+    pop, T = 2500, 25
+    case = cases.make_case(kind, pop*R, seed=21, policy='fnn', hidden=hidden, scale=0.3)
+    params = 0.3*np.random.default_rng(6).standard_normal((pop, case['ps'].num_param))
+    kwr = dict(policy_group=R, record=True)
+    ref = orc.rollout(kind, case['dt'], T, case['task_c'], case['ps'], params, case['init'], case['dp'], **kwr)
+    out = eng.rollout(kind, case['dt'], T, case['task_c'], case['ps'], params, case['init'], case['dp'], **kwr)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    for k in ('obs', 'act', 'rew', 'ret', 'final_state'):
+        assert cases.rel_err(out[k].cpu().numpy(), ref[k]) <= TOL, k
+    # another task (its shape is read at run time), large weights, a NaN in one policy: only its rollouts are affected
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    spec = envdefs.default_task_spec(kind)
+    task_c = dataclasses.replace(spec, rew_kind='exp', Q=np.diag(np.linspace(0.5, 2., S)), R=np.diag(np.full(A, 0.3))).to_c(S, A)
+    params = np.random.default_rng(7).standard_normal((pop, case['ps'].num_param))
+    params[11, 5] = np.nan
+    kwr = dict(policy_group=R)
+    T = 10
+    ref = orc.rollout(kind, case['dt'], T, task_c, case['ps'], params, case['init'], case['dp'], **kwr)
+    out = eng.rollout(kind, case['dt'], T, task_c, case['ps'], params, case['init'], case['dp'], **kwr)
+    np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    ret, ret_ref = out['ret'].cpu().numpy(), ref['ret']
+    np.testing.assert_array_equal(np.isnan(ret), np.isnan(ret_ref))
+    ok = ~np.isnan(ret_ref)
+    assert cases.rel_err(ret[ok], ret_ref[ok]) <= 1e-7   # saturated bang-bang actions amplify rounding
+
+
 def test_full_size_launch_is_order_invariant_and_matches_the_oracle_on_a_sample(eng, orc):
     """ The bench's launch size (2 097 152 QQube envs, FNN 64x64, T = 600): which lane, wave or workgroup runs an env
     must not influence its result, so a permuted launch returns the permuted results bit for bit; a sample of the
