@@ -742,7 +742,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
     // latency per layer: 100 us per step against 4)
     const int n_waves = (int)(blockDim.x >> 6);
     const int pop_shift = a.pop_tiles >> 1;     // log2 of 1, 2, 4
-    const int imgs = WREG ? NSET_OF(WREG) : (POP ? 4 >> pop_shift : 1);  // images per wave
+    const int imgs = WREG ? NSET_OF(WREG) : (POP ? a.pop_groups : 1);  // images per wave
     const int w_doubles = POP ? n_waves * imgs * a.lds_doubles : a.lds_doubles;
     double* const w_lds = lds + (POP ? wave * imgs * a.lds_doubles : 0);
     double* const stage = lds + w_doubles + wave * (OP * 64);
@@ -1419,12 +1419,16 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         a.lds_doubles = total - block_l1;
         a.pop_tiles = task_lanes / 16;
         a.pop_groups = two ? 2 : 1;
+        // (a population with a SIMD for every task: one policy per wave, whose step then carries one forward pass, not two)
+        const long tasks16 = (long)p.n_policies * ((p.policy_group + 15) / 16);
+        const int per_wave = (two && tasks16 > 4L * c->num_cus) ? 2 : 1;
+        if (two) a.pop_groups = per_wave;
         a.tanh_tab = c->tanh_tab;
         a.tanh_n = PSH_TANH8_N;
         const size_t lds_w = (4 * ((size_t)sets * a.lds_doubles + OP * 64) + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
         if (lds_w <= c->lds_per_block) {
             const long tasks = (long)p.n_policies * ((p.policy_group + task_lanes - 1) / task_lanes);
-            const long lanes = (tasks + sets - 1) / sets * 64;   // a wave takes `sets` tasks at a time
+            const long lanes = (tasks + per_wave - 1) / per_wave * 64;   // a wave takes `per_wave` tasks at a time
 #define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
             const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
             // (up to 8 rollouts per policy: the layers on 4x4x4 MFMAs, two column groups of 4 instead of a tile of 16)
@@ -1457,17 +1461,20 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         }
         if (W < 1) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
         const long GL = 16 * G, tasks = (long)p.n_policies * ((p.policy_group + GL - 1) / GL);
-        // no more waves per workgroup than keep every CU busy
-        while (W > 1 && tasks < (long)c->num_cus * W * (4 / G)) W -= 1;
-        const size_t waves_bytes = (size_t)W * ((size_t)(4 / G) * total + OP * 64) * sizeof(double);
+        // fewer groups per wave while that still gives every task a group at once (a wave's step carries the forward
+        // passes of all its groups, one after the other), and no more waves per workgroup than keep every CU busy
+        int groups = 4 / G;
+        while (groups > 1 && tasks <= 4L * c->num_cus * (groups / 2)) groups /= 2;
+        while (W > 1 && tasks < (long)c->num_cus * W * groups) W -= 1;
+        const size_t waves_bytes = (size_t)W * ((size_t)groups * total + OP * 64) * sizeof(double);
         fine = fine || waves_bytes + fixed_fine <= c->lds_per_block;  // fewer waves may leave room for the fine table
         const int BLOCK_POP = 64 * (int)W;
         a.pop_tiles = G;
-        a.pop_groups = 4 / G;
+        a.pop_groups = groups;
         a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
         a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
         const size_t lds_pop = waves_bytes + (fine ? fixed_fine : fixed_coarse);
-        const long lanes = (tasks + 4 / G - 1) / (4 / G) * 64;
+        const long lanes = (tasks + a.pop_groups - 1) / a.pop_groups * 64;
 #define PSH_LAUNCH_POP(HP_, FINE_, TANH_)                                                                                \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
