@@ -585,13 +585,16 @@ def test_ragged_and_empty_batches(eng, orc):
     assert out['ret'].numel() == 0
 
 
-@pytest.mark.parametrize('n', [15, 17, 4095, 4097, 16385, 32769, 65537, 98305, 131073])
-def test_small_and_medium_fnn_launches_at_the_edges_of_their_layouts(eng, orc, n):
+@pytest.mark.parametrize('n,hidden', [(15, (64, 64)), (17, (64, 64)), (4095, (64, 64)), (4097, (64, 64)), (8191, (64, 64)),
+                                      (8193, (64, 64)), (16385, (64, 64)), (32769, (64, 64)), (65537, (64, 64)),
+                                      (98305, (64, 64)), (131073, (64, 64)), (15, (64,)), (4097, (64, 32, 16)), (8191, (40, 64, 8))])
+def test_small_and_medium_fnn_launches_at_the_edges_of_their_layouts(eng, orc, n, hidden):
     """ FNN launches below two full waves per SIMD are spread over more waves with fewer MFMA tiles each (1-4 tiles per wave,
-    1, 4 or 8 waves per workgroup): batch sizes next to every switch of that layout, bare and behind a wrapper chain with
-    an action delay (whose ring buffers are indexed by the resident lane), against the oracle. """
+    1, 4 or 8 waves per workgroup); a 64-wide two-layer tanh network on up to 8 192 environments runs as a population of
+    copies of the policy with 8 rollouts each.  Batch sizes next to every switch of those layouts, bare and behind a
+    wrapper chain with an action delay (whose ring buffers are indexed by the resident lane), against the oracle. """
     kind, T = abi.ENV_QCP_ST, 12
-    case = cases.make_case(kind, n, seed=n, policy='fnn', hidden=(64, 64), scale=0.3)
+    case = cases.make_case(kind, n, seed=n, policy='fnn', hidden=hidden, scale=0.3)
     args = (kind, case['dt'], T, case['task_c'], case['ps'], case['params'], case['init'], case['dp'])
     for wrap in (None, cases.WrapSpec(ops=['act_delay', 'act_norm'], act_delay=2)):
         ref = orc.rollout(*args, wrap=wrap)
