@@ -126,7 +126,7 @@ def test_fnn_nan_parameter_is_flagged(eng, orc, hidden):
     assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)
 
 
-@pytest.mark.parametrize('policy', ['linear', 'fnn'])
+@pytest.mark.parametrize('policy', ['linear', 'fnn', 'fnn64'])
 @pytest.mark.parametrize('kind,wrap', cases.WRAP_CASES, ids=lambda v: '-'.join(v.ops) if hasattr(v, 'ops') else str(v))
 def test_rollout_with_fused_wrappers(eng, orc, kind, wrap, policy):
     """ ActNorm / ActDelay (fixed and per-env randomized) / Gaussian action and observation noise / ObsNorm /
@@ -137,9 +137,11 @@ def test_rollout_with_fused_wrappers(eng, orc, kind, wrap, policy):
     wrap = copy.deepcopy(wrap)
     wrap.env_offset = 12345678901
     kw = dict(obs_dim=wrap.obs_dim(O), scale=0.3)
-    if policy == 'fnn':
-        kw['hidden'] = (32, 32)
-    case = cases.make_case(kind, n, seed=55 + kind, policy=policy, **kw)
+    if policy != 'linear':
+        kw['hidden'] = (32, 32) if policy == 'fnn' else (64, 64)   # (64, 64): the kernel with the weights in registers
+        if policy == 'fnn64':
+            kw['scale'] = 0.1   # (QBallBalancer under a 64 x 64 net of larger weights amplifies rounding past the tolerance within 40 steps)
+    case = cases.make_case(kind, n, seed=55 + kind, policy=policy[:3] if policy != 'linear' else policy, **kw)
     dp = case['dp']
     if wrap.act_delay_row >= 0:
         dp = np.vstack([dp, np.random.default_rng(3).integers(0, 6, n).astype(float)[None, :]])
