@@ -496,6 +496,44 @@ def test_populations_of_up_to_8_rollouts_per_policy(eng, orc, kind, R, hidden):
     assert cases.rel_err(ret[ok], ret_ref[ok]) <= 1e-7   # saturated bang-bang actions amplify rounding
 
 
+def test_full_size_cem_generation_is_order_invariant_and_matches_the_oracle_on_a_sample(eng, orc):
+    """ A CEM generation at the size of the measurement plan: 4 096 FNN 64x64 policies x 8 rollouts on shared (domain
+    parameter, initial state) pairs, QBallBalancer behind ActDelay (per-rollout delay) and ActNorm.  More policies than
+    the chip holds at once, so register sets and LDS images are reloaded; which wave, half of a wave or turn runs a policy
+    must not influence its results: the generation with its policies permuted returns the permuted results bit for
+    bit.  A sample of the policies is checked against the oracle. """
+    import torch
+    kind, pop, R, T = abi.ENV_QBB, 4096, 8, 120
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    rng = np.random.default_rng(23)
+    dp = cases.domain_params(kind, R, rng)
+    dp = np.vstack([dp, rng.integers(0, 11, R).astype(float)[None, :]])
+    init = np.tile(cases.init_states(kind, dp[:P], rng), (1, pop))
+    dp_index = np.tile(np.arange(R), pop).astype(np.int32)
+    ps, theta0 = cases.fnn_policy(kind, rng, hidden=(64, 64), scale=0.1)
+    params = theta0[None, :] + 0.02*rng.standard_normal((pop, ps.num_param))
+    wrap = cases.WrapSpec(ops=['act_delay', 'act_norm'], act_delay_row=P)
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    dt = cases.DT[kind]
+    kw = dict(dp_index=dp_index, policy_group=R, wrap=wrap)
+    out = eng.rollout(kind, dt, T, task_c, ps, params, init, dp, **kw)
+    perm = rng.permutation(pop)
+    out_p = eng.rollout(kind, dt, T, task_c, ps, params[perm], init, dp, **kw)
+    for key in ('ret', 'length', 'status'):
+        assert torch.equal(out[key].view(pop, R)[torch.as_tensor(perm, device=out[key].device)], out_p[key].view(pop, R)), key
+    fs, fs_p = out['final_state'].view(-1, pop, R), out_p['final_state'].view(-1, pop, R)
+    assert torch.equal(fs[:, torch.as_tensor(perm, device=fs.device)], fs_p)
+    length = out['length'].cpu().numpy()
+    assert length.min() < T and length.max() == T        # some balls leave the plate, some rollouts run to the end
+    sample = np.sort(rng.choice(pop, 48, replace=False))
+    env_idx = (sample[:, None]*R + np.arange(R)[None, :]).ravel()
+    ref = orc.rollout(kind, dt, T, task_c, ps, params[sample], init[:, env_idx], dp, dp_index=dp_index[env_idx], policy_group=R,
+                      wrap=wrap)
+    np.testing.assert_array_equal(length[env_idx], ref['length'])
+    np.testing.assert_array_equal(out['status'].cpu().numpy()[env_idx], ref['status'])
+    assert cases.rel_err(out['ret'].cpu().numpy()[env_idx], ref['ret']) <= TOL
+
+
 def test_full_size_launch_is_order_invariant_and_matches_the_oracle_on_a_sample(eng, orc):
     """ The bench's launch size (2 097 152 QQube envs, FNN 64x64, T = 600): which lane, wave or workgroup runs an env
     must not influence its result, so a permuted launch returns the permuted results bit for bit; a sample of the
