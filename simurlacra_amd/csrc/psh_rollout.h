@@ -719,7 +719,8 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // WREG = 3: as WREG = 2 for up to 8 rollouts per policy, where half of the 16 columns of a 16x16x4 tile would be empty.
 // The layers run on v_mfma_f64_4x4x4_4b_f64 instead: four independent 4 x 4 x 4 blocks per instruction at the same
 // rate per multiply-add (16 cycles), here four groups of 4 hidden units against the same 4 rollouts, so a layer costs
-// two column groups of 4 instead of one of 16 -- half the MFMA time and half the activations.
+// two column groups of 4 instead of one of 16 -- half the MFMA time and half the activations.  WREG = 4: one column
+// group, for up to 4 rollouts per policy.
 constexpr int NSET_OF(int wreg) { return wreg >= 2 ? 2 : 1; }
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
 __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
     }
     // WREG = 3: the 4-lane block whose value a rotation by 4 rot lanes within the row of 16 delivers to this lane
     int b_from[4] = {0, 0, 0, 0};
-    if constexpr (WREG == 3) {
+    if constexpr (WREG >= 3) {
         b_from[0] = (lane >> 2) & 3;
         b_from[1] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 4, 0xf, 0xf, false) >> 2) & 3;
         b_from[2] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 8, 0xf, 0xf, false) >> 2) & 3;
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                         for (int j = OFF1 + lane; j < a.lds_doubles; j += 64) dst[j] = src[j + BLOCK];
                         // WREG = 3: register (rs, rp, rot) holds the lane's value of fragment (rs, 4 rp + block the rotation
                         // `rot` of the activations reads from), see run_narrow.  One base per rotation, constant offsets behind it.
-                        if constexpr (WREG == 3) {
+                        if constexpr (WREG >= 3) {
                             const double* base[4];
 #pragma unroll
                             for (int rot = 0; rot < 4; ++rot) base[rot] = src + OFF1 + b_from[rot] * 64 + lane;
@@ -998,9 +999,9 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
         // ks = 4 rp + b, those of the other blocks by rotating the row of 16 lanes by 4, 8 and 12 -- every block goes
         // through the 16 k-steps in an order of its own, which its weight registers follow (frag_of above).
         auto run_narrow = [&](const int p, const double* wr) {
-            if constexpr (WREG == 3) {
+            if constexpr (WREG >= 3) {
                 if (((live_mask >> (16 * p)) & 0xFFFFull) == 0) return;
-                constexpr int NG = 2;
+                constexpr int NG = WREG == 4 ? 1 : 2;   // column groups of 4 rollouts
                 const double* const wimg = w_lds + p * a.lds_doubles;
                 const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
                 const int unit = 4 * b + h;          // + 16 rs
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                 }
             }
         };
-        if constexpr (WREG == 3) {   // two policies of up to 8 rollouts, each with its own register set
+        if constexpr (WREG >= 3) {   // two policies of up to 8 (WREG = 4: up to 4) rollouts, each with its own register set
             run_narrow(0, wreg[0]);
             run_narrow(1, wreg[1]);
         } else if constexpr (WREG == 2) {   // two tiles, each with the register set of its own policy
@@ -1404,10 +1405,12 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     }
     // One such network on so few environments that every 8 of them get a SIMD: run as a population of copies of the policy
     // (image stride 0) with 8 rollouts each -- a wave-step is then the environment step plus a forward pass of 8 columns
-    // with the weights in registers, against one of 16 columns from LDS (QQube, T = 600: 1 000 rollouts 2.24 -> 1.89 ms,
-    // 4 096 rollouts 3.07 -> 2.37 ms).
+    // with the weights in registers, against one of 16 columns from LDS (QQube, T = 600: 1 000 rollouts 2.24 -> 1.31 ms,
+    // 4 096 rollouts 3.07 -> 1.83 ms).
     const bool copies = !per_env && HP == 64 && p.n_hidden == 2 && all_tanh && (long)d->n_envs <= 8 * simds;
-    const int grp = copies ? 8 : p.policy_group, npol = copies ? (int)(((long)d->n_envs + 7) / 8) : p.n_policies;
+    // (groups of 4 while every 4 of them get a SIMD: one column group)
+    const int grp = copies ? ((long)d->n_envs <= 4 * simds ? 4 : 8) : p.policy_group;
+    const int npol = copies ? (int)(((long)d->n_envs + grp - 1) / grp) : p.n_policies;
     if ((per_env || copies) && HP == 64 && p.n_hidden == 2 && all_tanh) {
         // population of two-hidden-layer tanh networks wider than 32: hidden-to-hidden weights in registers, one wave
         // per SIMD (see WREG at the kernel).  Up to 32 rollouts per policy: two policies per wave, 16 rollouts per task;
@@ -1439,6 +1442,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
 #define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
             const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
             // (up to 8 rollouts per policy: the layers on 4x4x4 MFMAs, two column groups of 4 instead of a tile of 16)
+            if (two && grp <= 4) return wrapped ? PSH_LAUNCH_WREG(true, 4, false) : (fixt ? PSH_LAUNCH_WREG(false, 4, true) : PSH_LAUNCH_WREG(false, 4, false));
             if (two && grp <= 8) return wrapped ? PSH_LAUNCH_WREG(true, 3, false) : (fixt ? PSH_LAUNCH_WREG(false, 3, true) : PSH_LAUNCH_WREG(false, 3, false));
             if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2, false) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
             return wrapped ? PSH_LAUNCH_WREG(true, 1, false) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
