@@ -629,7 +629,8 @@ template <int N> PSH_DEV double rotate_in_row(double x) {
 // all N values in registers at this point of the program (so that the loads that produce them are all in flight before
 // the first of them is used)
 template <int N> PSH_DEV void hold_together(double* v) {
-    static_assert(N == 4 || N == 8 || N == 16, "one statement per size");
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16, "one statement per size");
+    if constexpr (N == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1]));
     if constexpr (N == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
     if constexpr (N == 8)
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
@@ -720,12 +721,13 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // The layers run on v_mfma_f64_4x4x4_4b_f64 instead: four independent 4 x 4 x 4 blocks per instruction at the same
 // rate per multiply-add (16 cycles), here four groups of 4 hidden units against the same 4 rollouts, so a layer costs
 // two column groups of 4 instead of one of 16 -- half the MFMA time and half the activations.  WREG = 4: one column
-// group, for up to 4 rollouts per policy.
+// group, for up to 4 rollouts per policy.  The 32-wide networks (16 fragments, 32 registers per policy) run WREG = 2 and 3
+// with two waves per SIMD: their LDS images of 10 KB each kept only two or three waves of four policies on a CU.
 constexpr int NSET_OF(int wreg) { return wreg >= 2 ? 2 : 1; }
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
-__global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
+__global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
-    static_assert(!WREG || (POP && TANH && FINE && HP == 64), "WREG is the population kernel of the 64-wide tanh networks");
+    static_assert(!WREG || (POP && TANH && FINE && HP >= 32), "WREG is the population kernel of the 32- and 64-wide tanh networks");
     // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
     // vector ALU (16 FMAs each per tile) instead of through a k-step that is half zeros (QQube's 6 inputs: 4 + 2)
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = E::O / 4, REM = E::O % 4;
@@ -813,10 +815,10 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                             for (int rot = 0; rot < 4; ++rot) base[rot] = src + OFF1 + b_from[rot] * 64 + lane;
                             if (first < 16) {
 #pragma unroll
-                                for (int f = 0; f < HT * KS; ++f) wreg[0][f] = base[f & 3][((f >> 4) * KS + 4 * ((f >> 2) & 3)) * 64];
+                                for (int f = 0; f < HT * KS; ++f) wreg[0][f] = base[f & 3][((f / (4 * HT)) * KS + 4 * ((f >> 2) % HT)) * 64];
                             } else {
 #pragma unroll
-                                for (int f = 0; f < HT * KS; ++f) wreg[NSET - 1][f] = base[f & 3][((f >> 4) * KS + 4 * ((f >> 2) & 3)) * 64];
+                                for (int f = 0; f < HT * KS; ++f) wreg[NSET - 1][f] = base[f & 3][((f / (4 * HT)) * KS + 4 * ((f >> 2) % HT)) * 64];
                             }
                         } else if (NSET == 1 || first < 16) {
 #pragma unroll
@@ -1066,7 +1068,7 @@ __global__ __launch_bounds__(WREG ? 256 : ((WRAP || POP) ? 512 : 768)) void k_ro
                             for (int rs = 0; rs < HT; ++rs)
 #pragma unroll
                                 for (int g = 0; g < NG; ++g)
-                                    acc[rs][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr[(rs * 4 + rp) * 4 + rot], xb[g], acc[rs][g], 0, 0, 0);
+                                    acc[rs][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr[(rs * HT + rp) * 4 + rot], xb[g], acc[rs][g], 0, 0, 0);
                         }
                     }
 #pragma unroll
@@ -1447,6 +1449,36 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
             if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2, false) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
             return wrapped ? PSH_LAUNCH_WREG(true, 1, false) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
 #undef PSH_LAUNCH_WREG
+        }
+        a.lds_doubles = total;
+    }
+    // (one 32-wide policy on up to 8 environments per SIMD: as copies of the policy with 8 rollouts each, as above)
+    const bool copies32 = !per_env && HP == 32 && p.n_hidden == 2 && all_tanh && (long)d->n_envs <= 8 * simds;
+    const int grp32 = copies32 ? 8 : p.policy_group, npol32 = copies32 ? (int)(((long)d->n_envs + 7) / 8) : p.n_policies;
+    if ((per_env || copies32) && HP == 32 && p.n_hidden == 2 && all_tanh && grp32 <= 32) {
+        // the same for 32-wide networks with up to 32 rollouts per policy: two policies per wave, workgroups of 8 waves (two per
+        // SIMD with 256 registers each) -- 16 policies resident per CU on all four SIMDs, where their LDS images allowed 8 to 12
+        // on two or three
+        const int block_l1 = HT * KS * 64, waves = 8;
+        a.lds_doubles = total - block_l1;
+        a.pop_tiles = 1;
+        const long tasks = (long)npol32 * ((grp32 + 15) / 16);
+        const int per_wave = tasks > (long)waves * c->num_cus ? 2 : 1;
+        a.pop_groups = per_wave;
+        a.tanh_tab = c->tanh_tab;
+        a.tanh_n = PSH_TANH8_N;
+        const long lanes = (tasks + per_wave - 1) / per_wave * 64;
+        // no more waves per workgroup than keep every CU busy
+        int W = waves;
+        while (W > 1 && lanes / 64 < (long)c->num_cus * W) W -= 1;
+        const size_t lds_w = (W * (2 * (size_t)a.lds_doubles + OP * 64) + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
+        if (lds_w <= c->lds_per_block) {
+            if (copies32) { a.pol.policy_group = grp32; a.pol.n_policies = npol32; a.img_doubles = 0; }
+#define PSH_LAUNCH_WREG32(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 32, true, WRAP_, true, true, SETS_, FIXT_>, 64 * W, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
+            const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);
+            if (grp32 <= 8) return wrapped ? PSH_LAUNCH_WREG32(true, 3, false) : (fixt ? PSH_LAUNCH_WREG32(false, 3, true) : PSH_LAUNCH_WREG32(false, 3, false));
+            return wrapped ? PSH_LAUNCH_WREG32(true, 2, false) : (fixt ? PSH_LAUNCH_WREG32(false, 2, true) : PSH_LAUNCH_WREG32(false, 2, false));
+#undef PSH_LAUNCH_WREG32
         }
         a.lds_doubles = total;
     }

@@ -461,10 +461,11 @@ def test_large_fnn_population(eng, orc, kind, pop, R, hidden):
 
 @pytest.mark.parametrize('kind,R,hidden', [(abi.ENV_QQ, 8, (64, 64)), (abi.ENV_QQ, 5, (48, 40)), (abi.ENV_QBB, 8, (64, 64)),
                                            (abi.ENV_QBB, 3, (64, 64)), (abi.ENV_OMO, 1, (64, 64)), (abi.ENV_BOB, 7, (40, 64)),
-                                           (abi.ENV_QCP_SU, 4, (64, 64)), (abi.ENV_PEND, 8, (33, 17))])
+                                           (abi.ENV_QCP_SU, 4, (64, 64)), (abi.ENV_PEND, 8, (33, 17)), (abi.ENV_QQ, 8, (32, 32)),
+                                           (abi.ENV_QBB, 6, (24, 32)), (abi.ENV_OMO, 2, (32, 17)), (abi.ENV_QCP_ST, 13, (32, 32))])
 def test_populations_of_up_to_8_rollouts_per_policy(eng, orc, kind, R, hidden):
-    """ Two-hidden-layer tanh networks wider than 32 with at most 8 rollouts per policy run their layers in column groups
-    of 4 rollouts (4x4x4 MFMAs) instead of tiles of 16: every observation size (whole groups of 4 inputs and left-over
+    """ Two-hidden-layer tanh networks wider than 16 with at most 8 rollouts per policy run their layers in column groups
+    of 4 rollouts (4x4x4 MFMAs) instead of tiles of 16 (the last case: 13 rollouts, the 32-wide kernel with tiles of 16): every observation size (whole groups of 4 inputs and left-over
     inputs), full and partly filled column groups, padded layer widths, more policies than fit the chip at once, recorded
     trajectories; then a task that is not the simulation's default one, and weights large enough for the clamping tanh. """
     import dataclasses
@@ -627,11 +628,12 @@ def test_ragged_and_empty_batches(eng, orc):
 
 @pytest.mark.parametrize('n,hidden', [(15, (64, 64)), (17, (64, 64)), (4095, (64, 64)), (4097, (64, 64)), (8191, (64, 64)),
                                       (8193, (64, 64)), (16385, (64, 64)), (32769, (64, 64)), (65537, (64, 64)),
-                                      (98305, (64, 64)), (131073, (64, 64)), (15, (64,)), (4097, (64, 32, 16)), (8191, (40, 64, 8))])
+                                      (98305, (64, 64)), (131073, (64, 64)), (15, (64,)), (4097, (64, 32, 16)), (8191, (40, 64, 8)),
+                                      (8191, (32, 32)), (8193, (32, 24)), (37, (17, 32))])
 def test_small_and_medium_fnn_launches_at_the_edges_of_their_layouts(eng, orc, n, hidden):
     """ FNN launches below two full waves per SIMD are spread over more waves with fewer MFMA tiles each (1-4 tiles per wave,
-    1, 4 or 8 waves per workgroup); a 64-wide two-layer tanh network on up to 8 192 environments runs as a population of
-    copies of the policy with 8 rollouts each.  Batch sizes next to every switch of those layouts, bare and behind a
+    1, 4 or 8 waves per workgroup); a 32- or 64-wide two-layer tanh network on up to 8 192 environments runs as a population
+    of copies of the policy with 8 (or 4) rollouts each.  Batch sizes next to every switch of those layouts, bare and behind a
     wrapper chain with an action delay (whose ring buffers are indexed by the resident lane), against the oracle. """
     kind, T = abi.ENV_QCP_ST, 12
     case = cases.make_case(kind, n, seed=n, policy='fnn', hidden=hidden, scale=0.3)

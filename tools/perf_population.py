@@ -14,7 +14,7 @@ from tests import cases  # noqa: E402
 
 eng = get_engine(0)
 for kind, name, T in ((abi.ENV_QBB, 'QBB', 500), (abi.ENV_QQ, 'QQ', 600)):
-    for hidden in ((16, 16), (64, 64)):
+    for hidden in ((16, 16), (32, 32), (64, 64)) if len(sys.argv) < 2 else (tuple(int(h) for h in sys.argv[1].split(",")),):
         for pop, R in ((128, 8), (256, 16), (1024, 8), (4096, 4), (4096, 8), (4096, 16), (512, 64), (65536, 16)):
             case = cases.make_case(kind, pop*R, seed=1, policy='fnn', hidden=hidden, scale=0.2)
             params = torch.as_tensor(0.2*np.random.default_rng(0).standard_normal((pop, case['ps'].num_param)), device=eng.device)
