@@ -1503,6 +1503,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
             }
         }
         if (W < 1) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
+        // (a small population: the rollouts of a policy in tasks of fewer tiles while every task still gets a SIMD of its own)
+        while (G > 1 && (long)p.n_policies * ((p.policy_group + 8 * G - 1) / (8 * G)) <= 4L * c->num_cus) G /= 2;
         const long GL = 16 * G, tasks = (long)p.n_policies * ((p.policy_group + GL - 1) / GL);
         // fewer groups per wave while that still gives every task a group at once (a wave's step carries the forward
         // passes of all its groups, one after the other), and no more waves per workgroup than keep every CU busy
