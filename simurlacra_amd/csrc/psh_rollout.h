@@ -268,8 +268,12 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
         for (int j = wrap.n_ops - 1; j >= 0; --j) {
             const int op = wrap.ops[j];
             if (op == PSH_WRAP_OBS_NOISE) {
+                // the step made opaque inside the branch: the draws do not depend on j, and as loop-invariant, speculatable
+                // arithmetic they would be hoisted in front of the loop over the wrappers and run on every step of every launch
+                uint32_t tt = t;
+                asm volatile("" : "+v"(tt));
                 double n[E::O];
-                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, t, PSH_STREAM_OBS_NOISE, n);
+                step_normals<E::O>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, tt, PSH_STREAM_OBS_NOISE, n);
 #pragma unroll
                 for (int r = 0; r < E::O; ++r) o[r] = o[r] + (n[r] * wrap.obs_noise_std[r] + wrap.obs_noise_mean[r]);
             } else if (op == PSH_WRAP_OBS_NORM) {
@@ -363,8 +367,10 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
                 } else if (op == PSH_WRAP_ACT_NOISE) {
+                    uint32_t tt = (uint32_t)k;  // opaque inside the branch, as in wrapped_obs
+                    asm volatile("" : "+v"(tt));
                     double n[E::A];
-                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)k, PSH_STREAM_ACT_NOISE, n);
+                    step_normals<E::A>(wrap.noise_seed, wrap.env_offset + (uint64_t)i, tt, PSH_STREAM_ACT_NOISE, n);
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
                 }
