@@ -25,7 +25,9 @@ struct RolloutArgs {
     psh_policy pol;
     double bernoulli;      // rollout(bernoulli_reset): probability of ending the rollout after a step, 0 = off
     int obs_dim;           // entries of the observation the policy sees (all, or those kept by OBS_PARTIAL)
-    double* delay_q;       // ACT_DELAY: ring buffers [PSH_MAX_DELAY][A][n_lanes], one column per resident lane
+    int wrap_obs_ops;      // an observation wrapper (noise, normalisation, partial) is among wrap.ops: without one the
+                           // observation path of the wrapped kernels is that of the bare ones
+    double* delay_q;       // ACT_DELAY: ring buffers [n_lanes / 64][PSH_MAX_DELAY][A][64], one column per resident lane
     long n_lanes;
     int num_feat;          // LINEAR: total feature count F
     int lds_doubles;       // FNN: doubles of the packed weight image as a workgroup holds it in LDS
@@ -134,6 +136,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
     long i;           // env this lane currently runs, -1: none
     int curr_step, yielded, st, k;
     int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
+    double delay_pre[E::A];  // WRAP: the ring-buffer entry the next step will take out, requested a step ahead
     bool done, live;  // live: this lane still has steps to execute
     bool exhausted;   // the work queue had nothing left for this lane
     unsigned int chunk_next, chunk_end;  // wave-uniform: the envs of this wave's current chunk not handed out yet
@@ -251,6 +254,8 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
                 new_array = new_array || wrap.ops[j] == PSH_WRAP_ACT_NORM || wrap.ops[j] == PSH_WRAP_ACT_NOISE;
             }
             delay = 0; qpos = 0;
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) delay_pre[r] = 0.;
             if (has_delay) {  // ActDelayWrapper.reset / _load_domain_param (action_delay.py:46-64)
                 delay = wrap.act_delay_row >= 0 ? (int)a.domain_param[wrap.act_delay_row * a.ld_dp + col] : wrap.act_delay;
                 delay = delay < 0 ? 0 : (delay > PSH_MAX_DELAY ? PSH_MAX_DELAY : delay);
@@ -305,7 +310,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
 
     // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
     PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs) {
-        if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+        if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
         const int Oe = WRAP ? a.obs_dim : E::O;
         bool nan = false;
 #pragma unroll
@@ -352,15 +357,25 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
             for (int j = 0; j < wrap.n_ops; ++j) {
                 const int op = wrap.ops[j];
                 if (op == PSH_WRAP_ACT_DELAY && delay > 0) {  // FIFO as a ring: the slot written now is read `delay` steps on
-                    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                    // The entry taken out at step k was requested at the end of step k - 1 (delay_pre): the ring lives in
+                    // global memory, and a launch with a wave or two per SIMD would wait a memory round trip per step for it.
+                    // (a wave's rings are one contiguous block [PSH_MAX_DELAY][A][64]: the rows a wave walks through stay
+                    // within a page and a few dozen lines, whatever the size of the grid)
+                    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                    double* const ring = a.delay_q + wave * (long)(PSH_MAX_DELAY * E::A * 64) + (threadIdx.x & 63);
+                    double now[E::A];
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) {
-                        double* q = a.delay_q + ((long)qpos * E::A + r) * a.n_lanes + slot;
-                        const double old = (k >= delay) ? *q : 0.;
-                        *q = inner[r];
-                        inner[r] = old;
+                        ring[(qpos * E::A + r) * 64] = inner[r];
+                        now[r] = inner[r];
+                        inner[r] = (k >= delay) ? delay_pre[r] : 0.;
                     }
                     qpos = (qpos + 1 == delay) ? 0 : qpos + 1;
+                    if (k + 1 >= delay) {  // what step k + 1 takes out was written at step k + 1 - delay
+#pragma unroll
+                        for (int r = 0; r < E::A; ++r)
+                            delay_pre[r] = (delay == 1) ? now[r] : ring[(qpos * E::A + r) * 64];
+                    }
                 } else if (op == PSH_WRAP_ACT_NORM) {
                     double lo[E::A], hi[E::A];
                     e.act_bounds(lo, hi);
@@ -375,7 +390,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
                     for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
                 }
             }
-            rew = env_step<KIND>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
+            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
@@ -410,7 +425,7 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
     PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap) {
         if (a.obs) {  // final observation
             double obs[E::O];
-            if constexpr (WRAP) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+            if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
             const int Oe = WRAP ? a.obs_dim : E::O;
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
@@ -1290,6 +1305,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // wrappers, exploration noise and the stochastic reset live in the WRAP kernels
     const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
     a.obs_dim = Oe;
+    a.wrap_obs_ops = 0;
+    for (int j = 0; j < d->wrap.n_ops; ++j)
+        a.wrap_obs_ops |= d->wrap.ops[j] == PSH_WRAP_OBS_NOISE || d->wrap.ops[j] == PSH_WRAP_OBS_NORM || d->wrap.ops[j] == PSH_WRAP_OBS_PARTIAL;
     {
         const unsigned long N = (unsigned long)a.n_envs, T = (unsigned long)a.max_steps, O_ = (unsigned long)Oe, A_ = E::A;
         if ((d->obs || d->act || d->rew) && (O_ * N > 0xffffffffull || A_ * N > 0xffffffffull || (T + 1) * O_ > 0xffffffffull || T * A_ > 0xffffffffull)) {
@@ -1340,10 +1358,13 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         const bool simple = (p.n_feats == 1 && p.feats[0] == PSH_FEAT_IDENTITY) ||
                             (p.n_feats == 2 && p.feats[0] == PSH_FEAT_CONST && p.feats[1] == PSH_FEAT_IDENTITY);
         // the usual case gets a kernel of its own: bare simulation, const / identity features, the simulation's default task
-        const bool fixt = simple && !wrapped && task_has_default_shape<KIND>(d->task);
+        const bool fixt = simple && task_has_default_shape<KIND>(d->task);
 #define PSH_LAUNCH_LIN(PER_ENV_, WRAP_)                                                                                     \
     (simple ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st) \
             : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st))
+        if (fixt && wrapped)
+            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, true, true, true>, 256, 0, a, E::A, has_delay, st)
+                           : launch_persistent(c, k_rollout_linear<KIND, false, true, true, true>, 256, 0, a, E::A, has_delay, st);
         if (fixt)
             return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, false, true, true>, 256, 0, a, E::A, false, st)
                            : launch_persistent(c, k_rollout_linear<KIND, false, false, true, true>, 256, 0, a, E::A, false, st);
@@ -1448,12 +1469,12 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
             const long tasks = (long)npol * ((grp + task_lanes - 1) / task_lanes);
             const long lanes = (tasks + per_wave - 1) / per_wave * 64;   // a wave takes `per_wave` tasks at a time
 #define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
-            const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
+            const bool fixt = task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
             // (up to 8 rollouts per policy: the layers on 4x4x4 MFMAs, two column groups of 4 instead of a tile of 16)
-            if (two && grp <= 4) return wrapped ? PSH_LAUNCH_WREG(true, 4, false) : (fixt ? PSH_LAUNCH_WREG(false, 4, true) : PSH_LAUNCH_WREG(false, 4, false));
-            if (two && grp <= 8) return wrapped ? PSH_LAUNCH_WREG(true, 3, false) : (fixt ? PSH_LAUNCH_WREG(false, 3, true) : PSH_LAUNCH_WREG(false, 3, false));
-            if (two) return wrapped ? PSH_LAUNCH_WREG(true, 2, false) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
-            return wrapped ? PSH_LAUNCH_WREG(true, 1, false) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
+            if (two && grp <= 4) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 4, true) : PSH_LAUNCH_WREG(true, 4, false)) : (fixt ? PSH_LAUNCH_WREG(false, 4, true) : PSH_LAUNCH_WREG(false, 4, false));
+            if (two && grp <= 8) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 3, true) : PSH_LAUNCH_WREG(true, 3, false)) : (fixt ? PSH_LAUNCH_WREG(false, 3, true) : PSH_LAUNCH_WREG(false, 3, false));
+            if (two) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 2, true) : PSH_LAUNCH_WREG(true, 2, false)) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
+            return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 1, true) : PSH_LAUNCH_WREG(true, 1, false)) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
 #undef PSH_LAUNCH_WREG
         }
         a.lds_doubles = total;
@@ -1481,9 +1502,9 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         if (lds_w <= c->lds_per_block) {
             if (copies32) { a.pol.policy_group = grp32; a.pol.n_policies = npol32; a.img_doubles = 0; }
 #define PSH_LAUNCH_WREG32(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 32, true, WRAP_, true, true, SETS_, FIXT_>, 64 * W, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
-            const bool fixt = !wrapped && task_has_default_shape<KIND>(d->task);
-            if (grp32 <= 8) return wrapped ? PSH_LAUNCH_WREG32(true, 3, false) : (fixt ? PSH_LAUNCH_WREG32(false, 3, true) : PSH_LAUNCH_WREG32(false, 3, false));
-            return wrapped ? PSH_LAUNCH_WREG32(true, 2, false) : (fixt ? PSH_LAUNCH_WREG32(false, 2, true) : PSH_LAUNCH_WREG32(false, 2, false));
+            const bool fixt = task_has_default_shape<KIND>(d->task);
+            if (grp32 <= 8) return wrapped ? (fixt ? PSH_LAUNCH_WREG32(true, 3, true) : PSH_LAUNCH_WREG32(true, 3, false)) : (fixt ? PSH_LAUNCH_WREG32(false, 3, true) : PSH_LAUNCH_WREG32(false, 3, false));
+            return wrapped ? (fixt ? PSH_LAUNCH_WREG32(true, 2, true) : PSH_LAUNCH_WREG32(true, 2, false)) : (fixt ? PSH_LAUNCH_WREG32(false, 2, true) : PSH_LAUNCH_WREG32(false, 2, false));
 #undef PSH_LAUNCH_WREG32
         }
         a.lds_doubles = total;
