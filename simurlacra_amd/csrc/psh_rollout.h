@@ -1551,8 +1551,10 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, true, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, FINE_, false, true, TANH_>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
         // (the usual case again with kernels of its own: bare simulation, default task shape, all-tanh, fine table)
-        if (!wrapped && all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
-#define PSH_LAUNCH_POP_FIXT(HP_) launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true, true, 0, true>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes)
+        if (all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
+#define PSH_LAUNCH_POP_FIXT(HP_)                                                                                                           \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, true, true, 0, true>, BLOCK_POP, lds_pop, a, E::A, has_delay, st, lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, true, true, 0, true>, BLOCK_POP, lds_pop, a, E::A, false, st, lanes))
             if (HP == 16) return PSH_LAUNCH_POP_FIXT(16);
             if (HP == 32) return PSH_LAUNCH_POP_FIXT(32);
             return PSH_LAUNCH_POP_FIXT(64);
@@ -1577,8 +1579,10 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // the narrower kernels exist with the fine table only (on gfx950 their weight images always leave room for it)
     if (HP <= 32 && !fine) { set_err(c, "no LDS for the tanh table of this FNNPolicy"); return PSH_ERR_UNSUPPORTED; }
     // the usual case has kernels of its own: bare simulation with its default task shape, all-tanh network, fine table
-    if (!wrapped && all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
-#define PSH_LAUNCH_FNN_FIXT(HP_) launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes)
+    if (all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
+#define PSH_LAUNCH_FNN_FIXT(HP_)                                                                                                           \
+    (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, has_delay, st, work_lanes) \
+             : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes))
         if (HP == 16) return PSH_LAUNCH_FNN_FIXT(16);
         if (HP == 32) return PSH_LAUNCH_FNN_FIXT(32);
         return PSH_LAUNCH_FNN_FIXT(64);
