@@ -121,7 +121,7 @@ template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t
         double ua, ub, sn, cs;
         psh_draw2(seed, env, t, stream + 16u * p, ua, ub);
         const double r = sqrt(-2.0 * log(1.0 - ua));
-        sincos(2.0 * PSH_PI * ub, &sn, &cs);
+        psh_sincos(2.0 * PSH_PI * ub, &sn, &cs);  // (the argument lies in [0, 2 pi): the reduction's fast range)
         out[2 * p] = r * cs;
         if (2 * p + 1 < N) out[2 * p + 1] = r * sn;
     }
@@ -450,7 +450,11 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
 // the cheap simulations).
 // FIXT: the task has the default shape of this simulation (TaskShape), decided at compile time.
 template <int KIND, bool PER_ENV, bool WRAP, bool SIMPLE = false, bool FIXT = false>
-__global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : 2) void k_rollout_linear(const RolloutArgs a) {
+// (waves per SIMD the register allocation aims at: the wrapped kernels land a few registers above the 168 that three
+// waves per SIMD allow unless told to stay below, at the price of a few spills -- QQube behind ActNormWrapper, 2^20
+// rollouts: 8.5 -> 7.5 ms; the per-environment-policy variants mostly run populations of a wave or two per SIMD, which
+// gain nothing from a third wave and lose 12 % to the spills)
+__global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 3 : 2)) void k_rollout_linear(const RolloutArgs a) {
     using E = Env<KIND>;
     constexpr int W_DOUBLES = PSH_MAX_ACT * PSH_MAX_LIN_FEAT;
     __shared__ double lds_lin[W_DOUBLES + TASK_DOUBLES];
