@@ -1,0 +1,12 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -e
+for p in linear 16 32 64; do timeout -k 10 200 python -u tools/perf_cem.py 4096 8 $p 2>/dev/null; done > gpurun_out/perf_cem_after.txt
+echo cem done
+{ timeout -k 10 300 python -u tools/perf_wrapped.py 1048576 fnn 2>/dev/null; timeout -k 10 300 python -u tools/perf_wrapped.py 1048576 linear 2>/dev/null; } > gpurun_out/perf_wrapped_after.txt
+echo wrapped done
+timeout -k 10 400 python -u tools/bench_configs.py > gpurun_out/r02_bench_configs_now.txt 2>gpurun_out/bench_configs.err
+echo configs done
+timeout -k 10 250 python -u tools/perf_population.py > gpurun_out/r02_population_now.txt 2>/dev/null
+echo population done
+bash tools/profile_bench.sh r02final > gpurun_out/profile_bench_r02final.txt 2>&1
+echo profile done
