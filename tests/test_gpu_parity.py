@@ -731,6 +731,33 @@ def test_device_math_accuracy(eng):
     assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
 
 
+@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB], ids=['qq', 'qbb'])
+def test_a_wrapper_list_without_noise_does_not_pay_for_the_noise_draws(eng, kind):
+    """ The wrapped kernels carry the Philox + Box-Muller draws of GaussianObsNoiseWrapper / GaussianActNoiseWrapper; a
+    launch whose wrapper list holds neither must not execute them.  (They once ran on every step of every wrapped launch,
+    hoisted in front of the loop over the wrapper list: four to five times the instructions of the bare kernel.)  262 144
+    full-length LinearPolicy rollouts behind ActNormWrapper, timed with HIP events against the bare launch. """
+    import torch
+    from simurlacra_amd.specs import WrapSpec
+    n = 1 << 18
+    case = cases.make_case(kind, n, seed=4, policy='linear', feats=['identity'], scale=0.0)
+    args = (kind, case['dt'], 300, case['task_c'], case['ps'], torch.as_tensor(case['params'], device=eng.device),
+            torch.as_tensor(case['init'], device=eng.device), torch.as_tensor(case['dp'], device=eng.device))
+
+    def timed(**kw):
+        best = np.inf
+        for _ in range(3):
+            out = eng.rollout(*args, final_state=False, **kw)
+            best = min(best, eng.last_rollout_ms())
+        return best, out
+
+    t_bare, bare = timed()
+    t_norm, norm = timed(wrap=WrapSpec(ops=['act_norm']))
+    # zero weights: the normalised action 0 is the middle of the symmetric action range, the rollouts are the same
+    assert torch.equal(bare['length'], norm['length'])
+    assert t_norm < 1.9*t_bare, (t_bare, t_norm)
+
+
 @pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 300.)], ids=['omo', 'bob'])
 def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, min_gbs):
     """ 2^21 environments with full trajectories (T = 500): OneMassOscillator runs every episode to the end (34 GB of
