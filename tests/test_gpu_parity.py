@@ -149,6 +149,34 @@ def test_rollout_with_fused_wrappers(eng, orc, kind, wrap, policy):
     _compare_rollouts(eng, orc, case, T=T, wrap=wrap)
 
 
+@pytest.mark.parametrize('policy', ['linear', 'fnn', 'fnn64', 'population', 'population64'])
+@pytest.mark.parametrize('kind,spec,np_kw', [c for c in cases.custom_tasks() if c[0] in (abi.ENV_QQ, abi.ENV_QBB, abi.ENV_BOB)],
+                         ids=lambda v: cases.KIND_NAMES.get(v, '') if isinstance(v, int) else '')
+def test_fused_wrappers_around_a_task_without_the_default_shape(eng, orc, kind, spec, np_kw, policy):
+    """ The wrapped kernels exist twice: for the simulation's default task shape (decided at compile time) and for any
+    other task.  The wrapper tests above run the former; here a dense-weight custom task forces the latter, for a
+    LinearPolicy on the observations, FNNs from LDS and from registers, and populations of them. """
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    wrap = {abi.ENV_QQ: cases.WrapSpec(ops=['act_norm', 'act_delay'], act_delay=3),
+            abi.ENV_QBB: cases.WrapSpec(ops=['act_delay', 'act_norm', 'obs_noise'], act_delay=2, noise_seed=7, env_offset=3,
+                                        obs_noise_std=[0.01]*8),
+            abi.ENV_BOB: cases.WrapSpec(ops=['act_noise', 'act_norm'], noise_seed=2, act_noise_std=[0.05])}[kind]
+    R = 8
+    n, T = (40*R, 30) if policy.startswith('population') else (300, 30)
+    if policy == 'linear':
+        case = cases.make_case(kind, n, seed=31 + kind, policy='linear', feats=['identity'], scale=0.3)
+    else:
+        case = cases.make_case(kind, n, seed=31 + kind, policy='fnn', hidden=(64, 64) if policy.endswith('64') else (32, 32),
+                               scale=0.1)
+    case['task_c'] = spec.to_c(S, A)
+    kw = dict(wrap=wrap)
+    if policy.startswith('population'):
+        rng = np.random.default_rng(5)
+        case['params'] = 0.1*rng.standard_normal((n//R, case['ps'].num_param))
+        kw['policy_group'] = R
+    _compare_rollouts(eng, orc, case, T=T, **kw)
+
+
 @pytest.mark.parametrize('expl', ['normal', 'uniform'])
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
 def test_rollout_with_action_noise_exploration(eng, orc, expl, policy):
