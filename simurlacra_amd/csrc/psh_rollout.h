@@ -15,6 +15,13 @@
 #include "psh_rng.h"
 
 // ------------------------------------------------------------------------------------------ kernel arguments
+// Bit of RolloutArgs::flags set by the library alone (callers' flags are masked to the public PSH_F_* bits): the
+// wrapper list is exactly [ActNormWrapper] and nothing else needs the wrapped kernels.  ActNormWrapper in front of the
+// simulation is by far the most common wrapper configuration of the reference's training scripts, and it is one
+// multiply-add per action: the bare kernels apply it themselves instead of leaving such launches to the wrapped ones.
+#define PSH_F_INTERNAL_ACT_NORM (1 << 30)
+#define PSH_F_PUBLIC_MASK (PSH_F_STOP_ON_DONE | PSH_F_SIMPLIFIED_DYN | PSH_F_MAX_STEPS_INF | PSH_F_TRAJ_ENV_MAJOR)
+
 struct RolloutArgs {
     int n_envs, max_steps, flags, init_dim;
     double dt;
@@ -129,7 +136,8 @@ template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t
 
 // WRAP = true adds the fused environment wrappers (psh_wrappers) around the simulation; the bare variant carries
 // none of that code or state.
-template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
+// ANORM: the bare lane can apply a lone ActNormWrapper itself (PSH_F_INTERNAL_ACT_NORM)
+template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lane {
     using E = Env<KIND>;
     E e;
     double c_max, ret;
@@ -402,10 +410,23 @@ template <int KIND, bool WRAP, bool FIXT = false> struct Lane {
                 }
             }
         } else {
-            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, act, a.dt, a.max_steps, false, simplified, done, st);
+            // (a lone ActNormWrapper, environment_wrappers/action_normalization.py:10-22: the simulation receives a new
+            // array, so what it writes into its action -- QBallBalancer's dead zone -- does not reach the recorded one)
+            const bool act_norm = ANORM && (a.flags & PSH_F_INTERNAL_ACT_NORM) != 0;
+            double inner[E::A];
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) inner[r] = act[r];
+            if (act_norm) {
+                double lo[E::A], hi[E::A];
+                e.act_bounds(lo, hi);
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
+            }
+            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
+                for (int r = 0; r < E::A; ++r)
+                    traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act_norm ? act[r] : inner[r]);
             }
         }
         if (a.rew) traj_store(a.rew + traj_off(k, 0, i, a.rew_sk, 0u, a.rew_si), rew);
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
     }
     stage_task(a, lds_lin + W_DOUBLES);
     __syncthreads();
-    Lane<KIND, WRAP, FIXT> L;
+    Lane<KIND, WRAP, FIXT, !WRAP> L;
     L.init();
     const double* w = lds_w;
     long w_env = -1;
@@ -787,7 +808,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     stage_task(a, task_lds);
     __syncthreads();
 
-    Lane<KIND, WRAP, FIXT> L;   // FIXT: the simulation's default task shape compiled in (see k_rollout_linear)
+    Lane<KIND, WRAP, FIXT, !WRAP && !POP> L;   // FIXT: the simulation's default task shape compiled in (see k_rollout_linear)
     L.init();
     if (!POP && lane >= a.wave_lanes) L.exhausted = true;  // a small launch is spread over more waves, fewer tiles each
 
@@ -1307,7 +1328,14 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     if (p.expl_kind < PSH_EXPL_NONE || p.expl_kind > PSH_EXPL_UNIFORM) { set_err(c, "unknown exploration kind"); return PSH_ERR_ARG; }
     if (!(d->bernoulli_reset >= 0. && d->bernoulli_reset <= 1.)) { set_err(c, "bernoulli_reset must be within [0, 1]"); return PSH_ERR_ARG; }
     // wrappers, exploration noise and the stochastic reset live in the WRAP kernels
-    const bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
+    bool wrapped = d->wrap.n_ops > 0 || p.expl_kind != PSH_EXPL_NONE || d->bernoulli_reset > 0.;
+    // (a lone ActNormWrapper runs on the bare kernels)
+    // (LinearPolicy kernels and the single-policy FNN kernels; FNN populations keep the wrapped kernels)
+    if (d->wrap.n_ops == 1 && d->wrap.ops[0] == PSH_WRAP_ACT_NORM && p.expl_kind == PSH_EXPL_NONE && !(d->bernoulli_reset > 0.) &&
+        !(p.kind == PSH_POL_FNN && per_env)) {
+        wrapped = false;
+        a.flags |= PSH_F_INTERNAL_ACT_NORM;
+    }
     a.obs_dim = Oe;
     a.wrap_obs_ops = 0;
     for (int j = 0; j < d->wrap.n_ops; ++j)
@@ -1441,6 +1469,11 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     // with the weights in registers, against one of 16 columns from LDS (QQube, T = 600: 1 000 rollouts 2.24 -> 1.31 ms,
     // 4 096 rollouts 3.07 -> 1.83 ms).
     const bool copies = !per_env && HP == 64 && p.n_hidden == 2 && all_tanh && (long)d->n_envs <= 8 * simds;
+    const bool copies32_ = !per_env && HP == 32 && p.n_hidden == 2 && all_tanh && (long)d->n_envs <= 8 * simds;
+    if ((copies || copies32_) && (a.flags & PSH_F_INTERNAL_ACT_NORM)) {  // (population kernels: the lone ActNormWrapper stays a wrapper)
+        a.flags &= ~PSH_F_INTERNAL_ACT_NORM;
+        wrapped = true;
+    }
     // (groups of 4 while every 4 of them get a SIMD: one column group)
     const int grp = copies ? ((long)d->n_envs <= 4 * simds ? 4 : 8) : p.policy_group;
     const int npol = copies ? (int)(((long)d->n_envs + grp - 1) / grp) : p.n_policies;

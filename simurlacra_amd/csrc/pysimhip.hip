@@ -422,7 +422,7 @@ static int rollout_issue(psh_ctx* c, const psh_rollout_desc* d, hipStream_t st) 
     dims_of(d->env_kind, dm);
     RolloutArgs a;
     memset(&a, 0, sizeof a);
-    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags; a.init_dim = d->init_dim; a.dt = d->dt;
+    a.n_envs = d->n_envs; a.max_steps = d->max_steps; a.flags = d->flags & PSH_F_PUBLIC_MASK; a.init_dim = d->init_dim; a.dt = d->dt;
     a.init_state = d->init_state; a.ld_init = d->ld_init;
     a.domain_param = d->domain_param; a.dp_index = d->dp_index; a.ld_dp = d->ld_dp;
     a.task = d->task; a.wrap = d->wrap; a.pol = d->policy; a.bernoulli = d->bernoulli_reset;

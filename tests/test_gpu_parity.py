@@ -177,6 +177,28 @@ def test_fused_wrappers_around_a_task_without_the_default_shape(eng, orc, kind, 
     _compare_rollouts(eng, orc, case, T=T, **kw)
 
 
+@pytest.mark.parametrize('policy', ['linear', 'linear_simple', 'fnn', 'fnn64', 'population', 'population64'])
+@pytest.mark.parametrize('kind', cases.KINDS, ids=[cases.KIND_NAMES[k] for k in cases.KINDS])
+def test_a_lone_act_norm_wrapper(eng, orc, kind, policy):
+    """ ActNormWrapper alone in front of the simulation (the usual configuration of the reference's training scripts) runs
+    on the kernels of the bare simulation, which denormalise the action themselves: trajectories against the oracle, incl.
+    QBallBalancer, whose dead zone then no longer reaches the recorded action (the wrapper hands the simulation a new array). """
+    R = 8
+    n, T = (30*R, 40) if policy.startswith('population') else (300, 40)
+    if policy == 'linear':
+        case = cases.make_case(kind, n, seed=91 + kind, policy='linear', scale=0.3)
+    elif policy == 'linear_simple':
+        case = cases.make_case(kind, n, seed=91 + kind, policy='linear', feats=['const', 'identity'], scale=0.3)
+    else:
+        case = cases.make_case(kind, n, seed=91 + kind, policy='fnn', hidden=(64, 64) if policy.endswith('64') else (32, 32),
+                               scale=0.1)
+    kw = dict(wrap=cases.WrapSpec(ops=['act_norm']))
+    if policy.startswith('population'):
+        case['params'] = 0.1*np.random.default_rng(6).standard_normal((n//R, case['ps'].num_param))
+        kw['policy_group'] = R
+    _compare_rollouts(eng, orc, case, T=T, **kw)
+
+
 @pytest.mark.parametrize('expl', ['normal', 'uniform'])
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
 def test_rollout_with_action_noise_exploration(eng, orc, expl, policy):
