@@ -199,6 +199,15 @@ def test_a_lone_act_norm_wrapper(eng, orc, kind, policy):
     _compare_rollouts(eng, orc, case, T=T, **kw)
 
 
+@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB, abi.ENV_QCP_SU], ids=['qq', 'qbb', 'qcp-su'])
+@pytest.mark.parametrize('n,hidden', [(300, (16, 16)), (9000, (32, 32)), (9000, (64, 64)), (9000, (64, 48, 32))], ids=str)
+def test_a_lone_act_norm_wrapper_on_the_single_policy_fnn_kernels(eng, orc, kind, n, hidden):
+    """ Launches that take the bare single-policy FNN kernels with the action denormalised inside (more environments than
+    the population-of-copies layout of small launches serves, or a network it does not serve), recorded and compared in full. """
+    case = cases.make_case(kind, n, seed=17 + kind, policy='fnn', hidden=hidden, scale=0.1)
+    _compare_rollouts(eng, orc, case, T=30, wrap=cases.WrapSpec(ops=['act_norm']))
+
+
 @pytest.mark.parametrize('expl', ['normal', 'uniform'])
 @pytest.mark.parametrize('policy', ['linear', 'fnn'])
 def test_rollout_with_action_noise_exploration(eng, orc, expl, policy):
