@@ -146,7 +146,12 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
     double delay_pre[E::A];  // WRAP: the ring-buffer entry the next step will take out, requested a step ahead
     bool done, live;  // live: this lane still has steps to execute
-    bool exhausted;   // the work queue had nothing left for this lane
+    // the work queue had nothing left for this lane.  An integer on purpose: as a bool the flag lives as a 64-bit lane mask
+    // in scalar registers, and in the register-weight population kernels (90 spilled scalar registers) a build was seen in
+    // which single lanes of an idle group read it as set: they stayed out of the group's next task (their rollouts never
+    // ran) or, when the group's first lane was among them, the others took the queue position of an inactive lane (0) again
+    // and again and the launch never ended.  With the flag in a vector register the same build runs to the end.
+    int exhausted;
     unsigned int chunk_next, chunk_end;  // wave-uniform: the envs of this wave's current chunk not handed out yet
     bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
 
