@@ -5,3 +5,4 @@ from .features import (FeatureStack, MultFeat, RandFourierFeat, RBFFeat, abs_fea
 from .fnn import FNN, FNNPolicy
 from .linear import LinearPolicy
 from .initialization import init_param
+from .time import TimePolicy
