@@ -10,6 +10,12 @@ on-device domain randomization + init-state sampling + the fused rollout kernel 
 (+ one all-gather of those statistics across ranks).  Only env-steps executed before each env's `done` are counted.
 
 Prints ONE JSON line on rank 0.
+
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process starts N ranks itself, one per GPU
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, before anything here touches a GPU), relays rank 0's
+JSON line and fails if fewer than N GPUs are visible or any rank fails.  Under `python -m torch.distributed.run` the
+ranks are the launcher's; the line then reports the world size the collectives actually ran with (`rccl_ranks`), and a
+`--gpus` that disagrees with it is an error.
 """
 import argparse
 import json
@@ -31,7 +37,7 @@ FLOP_PER_STEP = 9352          # algorithmic fp64 flop per env-step, QQube + FNN 
 FP64_PEAK_TFLOPS = 78.6       # MI355X dense FP64 (matrix = vector rate: half the 157.3 TF FP32 peak)
 # HBM bytes per launch of the rollout kernel cannot be measured from inside this script: they come from the rocprofv3
 # counter passes over this same command (tools/profile_bench.sh), whose summary is committed next to the kernel trace.
-TRAFFIC_SUMMARIES = ['r02_bench_summary.json', 'r01_bench_summary.json']   # newest first, under profiles/
+TRAFFIC_SUMMARIES = ['r03_bench_summary.json', 'r02_bench_summary.json', 'r01_bench_summary.json']   # newest first, under profiles/
 DT, T = 1/500., 600
 
 
@@ -69,7 +75,7 @@ def qq_set_distrs(set_id):
     return distrs, list(nom.values())
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -77,33 +83,93 @@ def main():
     ap.add_argument('--sets', type=int, default=8, help='domain-parameter sets per GPU')
     ap.add_argument('--rollouts', type=int, default=262144, help='rollouts per domain-parameter set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend of the ranks; 'gloo' with --stub-engine rehearses the multi-rank "
+                         'plumbing on a machine without GPUs (tests/test_distributed.py)')
+    ap.add_argument('--stub-engine', action='store_true', help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """ One child process per GPU, started before this process has touched a GPU.  Rank 0's stdout is this run's stdout. """
+    import subprocess
+    n = args.gpus
+    if not args.stub_engine:
+        have = torch.cuda.device_count()     # (counting devices does not initialise the GPU)
+        if have < n:
+            sys.exit(f'bench.py: --gpus {n} asked for, but only {have} GPU(s) are visible to this process')
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.stdout.write(out0)
+        sys.exit(f'bench.py: ranks exited with {codes}')
+    lines = [ln for ln in out0.splitlines() if ln.startswith('{')]
+    if len(lines) != 1 or json.loads(lines[0]).get('n_gpus') != n or json.loads(lines[0]).get('rccl_ranks') != n:
+        sys.stdout.write(out0)
+        sys.exit(f'bench.py: expected one JSON line from rank 0 reporting {n} ranks')
+    print(lines[0], flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args, argv)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if '--gpus' in ' '.join(argv) and args.gpus != world:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)')
+    gpu = not args.stub_engine
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
     # under torch.distributed.run the collectives run even with a single rank, so one GPU exercises the RCCL path
     if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
+        if gpu and torch.cuda.device_count() <= local_rank:
+            sys.exit(f'bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)')
+        if gpu:
+            torch.cuda.set_device(local_rank)
         # RCCL writes a version banner to stdout when its communicator is created: send it to stderr, stdout carries
         # the one JSON line only
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            if gpu and args.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group(args.backend)
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
     else:
         dist = None
-    torch.cuda.set_device(local_rank)
-    eng = get_engine(local_rank)
+    if gpu:
+        torch.cuda.set_device(local_rank)
+        eng = get_engine(local_rank)
+    else:
+        eng = StubEngine()
     dev = eng.device
 
     S, O, A, P, _ = abi.ENV_DIMS[abi.ENV_QQ]
@@ -137,31 +203,43 @@ def main():
         one_step(-1 - w)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
     for it in range(args.steps):
         steps, stats = one_step(it)
         total_steps += steps
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
 
-    # whole-job numbers: max time over ranks, sum of executed env-steps over ranks
+    # whole-job numbers: max time over ranks, sum of executed env-steps over ranks, ranks that took part in the collectives
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ranks = torch.ones((), dtype=torch.int64, device=dev)
+    local_steps = int(total_steps.item())
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     total = int(total_steps.item())
+    rccl_ranks = int(ranks.item())
+    if rccl_ranks != world:
+        sys.exit(f'bench.py: {rccl_ranks} ranks took part in the collectives, {world} were started')
 
-    # dominant kernel: one more pass, its duration taken from HIP events recorded on the launch stream
-    steps_k, _ = one_step(args.steps)
-    k_ms = eng.last_rollout_ms()
-    steps_k = int(steps_k.item())
+    # dominant kernel: the rollout launches of the K timed steps themselves (rank 0's), each bracketed by HIP events on
+    # the launch stream inside the library; read back only now, so the timed region ran without a host wait in it
+    k_all = [eng.rollout_ms(back) for back in range(min(args.steps, 64))]
+    assert all(v > 0. for v in k_all), k_all
+    k_ms = float(np.mean(k_all))
+    steps_k = local_steps/args.steps                      # env-steps of one launch, mean over the same launches
     achieved = FLOP_PER_STEP*steps_k/(k_ms*1e-3)/1e12
+
+    executed = executed_fp64()
+    if executed['executed_flop_per_env_step']:
+        executed['executed_fp64_frac'] = executed['executed_flop_per_env_step']*steps_k/(k_ms*1e-3)/1e12/FP64_PEAK_TFLOPS
 
     traffic = traffic_source = None
     if (n_sets, R) == (8, 262144):  # the committed counter runs hold for the default workload only
@@ -177,24 +255,114 @@ def main():
     if rank == 0:
         res = {
             'metric': 'domain-randomized env-steps/sec (QQube, FNN policy)',
-            'value': total/elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': total/elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks if dist is not None else 0,
+            'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3*elapsed/args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64', 'data': 'synthetic' if gpu else 'stub engine on CPUs: a rehearsal of the multi-rank plumbing, no measurement',
             'config': {'workload': 'QQubeSim dt=1/500 T=600, DomainRandomizer (default QQ randomizer, per-set Mp/Mr/Lp/Lr '
                                    'mean/std +-30%), FNNPolicy 6-64-64-1 tanh (orthogonal init seed 0)',
                        'domain_param_sets_per_gpu': n_sets, 'rollouts_per_set': R, 'envs_per_gpu': N,
                        'env_steps_counted': 'executed before done', 'parallelism': f'env-sharded x{world}'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': 'k_rollout_fnn<QQ,64>', 'kernel_ms': k_ms, 'env_steps_per_launch': steps_k,
-                         'flop_per_env_step': FLOP_PER_STEP},
+                         'kernel': 'k_rollout_fnn<QQ,64>', 'kernel_ms': k_ms, 'kernel_ms_min_max': [min(k_all), max(k_all)],
+                         'kernel_launches_timed': len(k_all), 'env_steps_per_launch': steps_k,
+                         'flop_per_env_step': FLOP_PER_STEP, **executed},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and gpu:
             res['cpu_baseline'] = cpu_baseline(eng, sets, task_c, ps, params)
+            try:
+                res['cpu_baseline']['slices'] = cpu_strong_slices(eng)
+            except Exception as exc:  # a courtesy leg, as the pool below: its failure must not lose the GPU numbers
+                res['cpu_baseline']['slices'] = {'error': repr(exc)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class StubEngine:
+    """ Stands in for the GPU engine when the multi-rank plumbing of this script is rehearsed on CPUs (--stub-engine with
+    --backend gloo): results are functions of the global env index, kernel time is a constant.  Measures nothing. """
+    device = torch.device('cpu')
+
+    def randomize(self, n_envs, distrs, nominal_rows, seed, env_offset=0):
+        out = torch.tensor(nominal_rows, dtype=torch.float64).reshape(-1, 1).repeat(1, n_envs)
+        out[0] = env_offset + torch.arange(n_envs, dtype=torch.float64)
+        return out
+
+    def sample_init(self, env_kind, n_envs, domain_param, seed, env_offset=0, dp_index=None):
+        return torch.zeros((abi.ENV_DIMS[env_kind][4], n_envs), dtype=torch.float64)
+
+    def rollout(self, env_kind, dt, max_steps, task_c, policy_spec, params, init_state, domain_param, *, final_state=True, out=None):
+        g = domain_param[0]
+        return dict(ret=g.clone(), length=(g.to(torch.int32) % int(max_steps)) + 1, status=torch.zeros(g.numel(), dtype=torch.int32))
+
+    def rollout_ms(self, back=0):
+        return 1.0
+
+
+def executed_fp64():
+    """ Hardware fp64 flop the kernel executes per env-step, from the committed instruction-counter profile of this
+    command (tools/pmc_insts.sh): MFMAs at 2 x 16 x 16 x 4 flop, vector FMA at 2 and MUL / ADD at 1 flop per lane.  (That
+    counter run tallies every instruction twice; its per-wave-step column is halved here.)  Next to the algorithmic
+    `frac` it says how much of the pipe the launch keeps busy with arithmetic of any kind. """
+    for name in ('r03_bench_instruction_mix.txt', 'r02_bench_instruction_mix.txt'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        per_ws = {}
+        with open(path) as f:
+            for line in f:
+                w = line.split()
+                if len(w) >= 5 and w[0].startswith('SQ_') and w[2:4] == ['per', 'wave-step']:
+                    per_ws[w[0]] = float(w[4])/2.
+        try:
+            flop_ws = (per_ws['SQ_INSTS_MFMA']*2*16*16*4 + 64*(2*per_ws['SQ_INSTS_VALU_FMA_F64'] + per_ws['SQ_INSTS_VALU_MUL_F64']
+                                                               + per_ws['SQ_INSTS_VALU_ADD_F64']))
+        except KeyError:
+            continue
+        return {'executed_flop_per_env_step': flop_ws/64., 'executed_fp64_source': f'profiles/{name} (counter passes over this command, not this run)'}
+    return {'executed_flop_per_env_step': None, 'executed_fp64_source': None}
+
+
+def cpu_strong_slices(eng, n=10_000):
+    """ 10 000-environment slices of the other workloads of the measurement plan -- OneMassOscillator and BallOnBeam with
+    a LinearPolicy on identity features (T = 500), QCartPoleSwingUp with the FNN 64x64 (T = 1 000) -- on the C restatement
+    with OpenMP over all host cores and, on the same inputs, through the rollout kernel; returns must agree. """
+    from oracle import oracle_lib as orc
+    from simurlacra_amd.domain_randomization import get_default_randomizer
+    from simurlacra_amd.environments import BallOnBeamSim, OneMassOscillatorSim, QCartPoleSwingUpSim
+    threads = orc.lib().orc_num_threads()
+    res = []
+    for tag, env, T, pol in (('OneMassOscillatorSim dt=0.01 T=500, LinearPolicy(identity)', OneMassOscillatorSim(dt=0.01, max_steps=500), 500, 'linear'),
+                             ('BallOnBeamSim dt=0.01 T=500, LinearPolicy(identity)', BallOnBeamSim(dt=0.01, max_steps=500), 500, 'linear'),
+                             ('QCartPoleSwingUpSim dt=1/500 T=1000, FNNPolicy 64x64 tanh', QCartPoleSwingUpSim(dt=1/500., max_steps=1000), 1000, 'fnn')):
+        kind = env.kind
+        S, O, A, P, _ = abi.ENV_DIMS[kind]
+        rand = get_default_randomizer(env)
+        dp = eng.randomize(n, rand.device_table(envdefs.DP_NAMES[kind], ()), list(env.domain_param_column()), seed=7)
+        init = eng.sample_init(kind, n, dp, seed=7)
+        task_c = env.task_spec().to_c(S, A)
+        if pol == 'fnn':
+            ps = PolicySpec('fnn', O, A, hidden=[64, 64], hidden_nonlin=['tanh', 'tanh'])
+            w = reference_fnn_params([O, 64, 64, A], seed=0)
+        else:
+            ps = PolicySpec('linear', O, A, feats=['identity'])
+            w = 0.1*torch.randn(ps.num_param, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+        for _ in range(2):
+            out = eng.rollout(kind, env.dt, T, task_c, ps, w.to(eng.device), init, dp, final_state=False)
+        ms = eng.rollout_ms(0)
+        g_ret, g_len = out['ret'].cpu().numpy(), out['length'].cpu().numpy()
+        t0 = time.perf_counter()
+        o = orc.rollout(kind, env.dt, T, task_c, ps, w.numpy(), init.cpu().numpy(), dp.cpu().numpy(), n_threads=threads)
+        el = time.perf_counter() - t0
+        res.append({'workload': tag, 'envs': n, 'env_steps': int(o['length'].sum()), 'cpu_value': float(o['length'].sum()/el),
+                    'cpu_seconds': el, 'cores': threads, 'gpu_value': float(g_len.sum()/(ms*1e-3)), 'gpu_kernel_ms': ms,
+                    'unit': 'env-steps/s', 'lengths_equal': bool(np.array_equal(g_len, o['length'])),
+                    'return_mean_std_cpu': [float(o['ret'].mean()), float(o['ret'].std())],
+                    'return_mean_std_gpu': [float(g_ret.mean()), float(g_ret.std())]})
+    return res
 
 
 def host_cpu():

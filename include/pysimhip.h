@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 110
+#define PSH_VERSION 111
 
 #define PSH_MAX_STATE 8   /* largest state vector (QBallBalancer)                 */
 #define PSH_MAX_OBS 8     /* largest observation vector                            */
@@ -200,6 +200,9 @@ typedef struct psh_policy {
 #define PSH_ST_BERNOULLI 8 /* rollout ended by the stochastic reset (bernoulli_reset)           */
 #define PSH_ST_BAD_INDEX 16 /* dp_index[i] or policy_index[i] points outside its table: the env is
                               not run (length 0, return 0); nothing outside the tables is read  */
+#define PSH_ST_INTERNAL 32 /* the lanes of a wave disagreed about a decision that is theirs in common (population mode:
+                             whether their group still draws from the work queue).  Never set by a correct run; the
+                             kernel carries on from the wave-wide view, the host layer raises on it.               */
 
 /* Environment wrappers fused into the rollout (Pyrado/pyrado/environment_wrappers/): what EnvWrapperAct.step
  * and EnvWrapperObs.reset/step (base.py:145-231) do around the simulation each step.  `ops` lists the wrappers
@@ -316,7 +319,11 @@ int psh_rollout(psh_ctx* ctx, const psh_rollout_desc* desc);
  * PSH_STATIC_MAX_WEIGHT_DOUBLES doubles (any single FNN the kernels support fits; a population of 64x64 networks up to
  * about 3), QBallBalancerSim with the full dynamics at most PSH_STATIC_MAX_QBB_ENVS environments, no fused
  * ActDelayWrapper (its ring buffers scale with the launch).  All calls on one GPU share the array, whatever their
- * context: calls that overlap in time on one GPU race; calls of one context are ordered by the library. */
+ * context: the library orders them per GPU (each waits for an event recorded behind the previous one, on whatever
+ * stream or context that was issued), so they run one after the other.  On a stream that is being captured into a graph
+ * the call enqueues its memset and kernels only -- no event is waited for or recorded, no timing is taken -- and the
+ * caller orders the replays of that graph against every other call that uses the array: replays that overlap with one
+ * another or with another static call on the same GPU race. */
 #define PSH_STATIC_MAX_WEIGHT_DOUBLES 16384
 #define PSH_STATIC_MAX_QBB_ENVS 524288
 int psh_rollout_static(psh_ctx* ctx, const psh_rollout_desc* desc);
@@ -448,6 +455,17 @@ int psh_eval_math(psh_ctx* ctx, int32_t fn, int32_t n, const double* x /*[dev][n
 /* Elapsed time of the most recent psh_rollout kernel of this ctx in milliseconds, measured with HIP
  * events on the launch stream; synchronises on the stop event.  Returns < 0 if none was recorded. */
 float psh_last_rollout_ms(psh_ctx* ctx);
+
+/* The same for the rollout launched `back` launches before the most recent one of this ctx (0 = the most recent; the
+ * library keeps the event pairs of the last 64 launches), so that a caller can issue a series of rollouts without
+ * waiting in between and read every launch's kernel time afterwards -- what the reference's rollout(record_dts=True)
+ * collects per step with time.time() (Pyrado/pyrado/sampling/rollout.py:125-138,196-216), here per launch.
+ * Launches issued while their stream was being captured into a graph record no events and are not counted. */
+float psh_rollout_ms(psh_ctx* ctx, int32_t back);
+
+/* Diagnostic, no counterpart in the reference: the number of device allocations (hipMalloc) the library has made for
+ * this ctx's scratch buffers since psh_create.  psh_rollout grows them on demand; psh_rollout_static never does. */
+int64_t psh_alloc_count(const psh_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ Field order and types must match the header exactly.
 """
 import ctypes as C
 
-PSH_VERSION = 110
+PSH_VERSION = 111
 PSH_MAX_STATE = 8
 PSH_MAX_OBS = 8
 PSH_MAX_ACT = 2
@@ -30,7 +30,7 @@ FEAT_IDS = dict(const=0, identity=1, sign=2, abs=3, squared=4, cubed=5, sig=6, b
                 sincos=11, mult=12, rff=13, rbf=14)
 NL_IDS = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 F_STOP_ON_DONE, F_SIMPLIFIED_DYN, F_MAX_STEPS_INF, F_TRAJ_ENV_MAJOR = 1, 2, 4, 8
-ST_NAN, ST_FAILED, ST_TIMEOUT, ST_BERNOULLI, ST_BAD_INDEX = 1, 2, 4, 8, 16
+ST_NAN, ST_FAILED, ST_TIMEOUT, ST_BERNOULLI, ST_BAD_INDEX, ST_INTERNAL = 1, 2, 4, 8, 16, 32
 DISTR_CONST, DISTR_NORMAL, DISTR_UNIFORM, DISTR_BERNOULLI = range(4)
 WRAP_ACT_NORM, WRAP_ACT_DELAY, WRAP_ACT_NOISE, WRAP_OBS_NOISE, WRAP_OBS_NORM, WRAP_OBS_PARTIAL = range(1, 7)
 
@@ -145,5 +145,7 @@ PSH_SYMBOLS = {
     'psh_topk': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'psh_bootstrap_means': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     'psh_last_rollout_ms': (C.c_float, [C.c_void_p]),
+    'psh_rollout_ms': (C.c_float, [C.c_void_p, C.c_int32]),
+    'psh_alloc_count': (C.c_int64, [C.c_void_p]),
     'psh_eval_math': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -9,6 +9,7 @@
 #include "../../include/pysimhip.h"
 
 // ------------------------------------------------------------------------------------------------ context
+#define PSH_TIMING_RING 64
 struct psh_ctx {
     int device;
     char err[512];
@@ -22,8 +23,14 @@ struct psh_ctx {
     double* tanh_tab;    // [tanh(j/256), j = 0..5120 (psh_tanh8)][tanh(j/64), j = 0..1280 (psh_tanh_tab)]
     int num_cus;
     size_t lds_per_block;
+    // HIP events around the rollout kernel of the last PSH_TIMING_RING launches (psh_rollout_ms); ev0 / ev1 = the pair of
+    // the launch being issued, timed = 0 while the stream is being captured into a graph (events recorded there could
+    // not be waited for)
+    hipEvent_t tev0[PSH_TIMING_RING], tev1[PSH_TIMING_RING];
+    long n_timed;
     hipEvent_t ev0, ev1;
     int timed;
+    long n_allocs;       // device allocations made for this context's scratch so far (psh_alloc_count)
     // Every rollout of a context uses the context's scratch (queue counter, weight image, plate angles, delay rings):
     // a rollout issued on another stream waits for this event, recorded behind the previous rollout's kernel.
     hipEvent_t ev_done;
@@ -59,6 +66,7 @@ static inline int ensure_doubles(psh_ctx* c, double** buf, size_t* have, size_t 
     if (*buf) PSH_HIP(c, hipFree(*buf));
     *buf = nullptr; *have = 0;
     PSH_HIP(c, hipMalloc(buf, need * sizeof(double)));
+    c->n_allocs += 1;
     *have = need;
     return PSH_OK;
 }

@@ -156,7 +156,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
 
     static constexpr int QUEUE_CHUNK = 8;
-    PSH_DEV void init() { i = -1; live = false; exhausted = false; chunk_next = chunk_end = 0; }
+    PSH_DEV void init() { i = -1; live = false; exhausted = 0; chunk_next = chunk_end = 0; }
 
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
@@ -193,7 +193,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
                 chunk_next = base < n ? base : n;
                 chunk_end = base + size < n ? base + size : n;
                 if (chunk_next == chunk_end) {  // the queue is empty
-                    if (want) exhausted = true;
+                    if (want) exhausted = 1;
                     break;
                 }
             }
@@ -216,26 +216,44 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     // weight image the wave keeps in LDS.  Task q = (policy q / chunks, rollouts 16 G (q % chunks) ... of that policy);
     // a group takes the next task when none of its lanes has an env.  Returns the policy of this lane's group;
     // *fresh has the bit of a group's first lane set if the group took a new task (the caller loads its weight image).
+    //
+    // Must be called with all 64 lanes of the wave active.  Everything a group decides is computed from ballots over the
+    // whole wave, so the lanes of a group cannot come to different conclusions whatever their own flags hold: which
+    // groups are idle, which of them still draw from the queue, and how many queue positions the wave takes (ONE atomic
+    // per wave, issued by lane 0 under a wave-uniform condition; group g of the taking groups gets position base + its
+    // rank).  An earlier form tested the per-lane `exhausted` flag inside the divergent region of each group and broadcast
+    // the queue position with a shuffle from the group's first lane: a single lane with a wrong flag then stayed out of
+    // its group's tasks, and a wrong flag in the first lane made the others read position 0 from an inactive lane for
+    // ever.  Here a group counts as exhausted only if ALL its lanes say so (a draw from the empty queue costs nothing and
+    // sets the flag in every lane again), and a disagreement is remembered in `fault` (kept by the caller, per lane) and
+    // goes into the status word of every rollout the lane stores from then on (PSH_ST_INTERNAL).
     PSH_DEV int turnover_group(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, int pol,
-                               unsigned long long* fresh) {
-        if (i >= 0 && !live) { store(a, wrap); i = -1; }
+                               unsigned long long* fresh, int& fault) {
+        if (i >= 0 && !live) { store(a, wrap, fault); i = -1; }
         const int lane = threadIdx.x & 63, GL = 16 * a.pop_tiles;
         const int first = lane & ~(GL - 1);
-        const unsigned long long busy = __ballot(i >= 0);
         const unsigned long long group = (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)) << first;
+        const unsigned long long busy = __ballot(i >= 0), exh = __ballot(exhausted != 0);
+        const unsigned long long exh_g = exh & group;
+        if (exh_g != 0 && exh_g != group) fault |= PSH_ST_INTERNAL;
+        const bool take = (busy & group) == 0 && exh_g != group && first < GL * a.pop_groups;
+        const unsigned long long heads = __ballot(take && lane == first);
+        *fresh = 0;
+        if (heads == 0) return pol;  // (wave-uniform)
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(a.queue, (unsigned int)__popcll(heads));
+        base = __builtin_amdgcn_readfirstlane(base);
         bool got = false;
-        if ((busy & group) == 0 && !exhausted && first < GL * a.pop_groups) {  // the same for all lanes of a group
+        if (take) {
             const int R = a.pol.policy_group, chunks = (R + GL - 1) / GL;
-            unsigned int q = 0;
-            if (lane == first) q = atomicAdd(a.queue, 1u);
-            q = __shfl(q, first);
+            const unsigned int q = base + (unsigned int)__popcll(heads & ((1ull << first) - 1ull));
             if (q < (unsigned int)(a.pol.n_policies * chunks)) {
                 pol = (int)(q / chunks);
                 const int r = GL * (int)(q % chunks) + (lane - first);
                 if (r < R && (long)pol * R + r < (long)a.n_envs) { i = (long)pol * R + r; load(a, task, wrap); }
                 got = lane == first;
             } else {
-                exhausted = true;
+                exhausted = 1;
             }
         }
         *fresh = __ballot(got);
@@ -448,7 +466,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         }
     }
 
-    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap) {
+    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap, int extra_status = 0) {
         if (a.obs) {  // final observation
             double obs[E::O];
             if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
@@ -459,7 +477,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         }
         a.ret[i] = ret;
         a.length[i] = k;
-        a.status[i] = st;
+        a.status[i] = st | extra_status;
         if (a.final_state) {
 #pragma unroll
             for (int r = 0; r < E::S; ++r) a.final_state[(long)r * a.n_envs + i] = e.s[r];
@@ -815,10 +833,11 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
 
     Lane<KIND, WRAP, FIXT, !WRAP && !POP> L;   // FIXT: the simulation's default task shape compiled in (see k_rollout_linear)
     L.init();
-    if (!POP && lane >= a.wave_lanes) L.exhausted = true;  // a small launch is spread over more waves, fewer tiles each
+    if (!POP && lane >= a.wave_lanes) L.exhausted = 1;  // a small launch is spread over more waves, fewer tiles each
 
     const int n_hidden = a.pol.n_hidden;
     int pol = 0;  // POP: policy of this lane's group of tiles
+    int fault = 0;  // POP: PSH_ST_INTERNAL once the lanes of this lane's group were seen to disagree (see turnover_group)
     // WREG: fragment (t, s) of the hidden-to-hidden weights of this wave's policy / of the policies of its tiles 0 and 1
     constexpr int NSET = NSET_OF(WREG);
     double wreg[NSET][WREG ? HT * KS : 1];
@@ -846,7 +865,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     for (;;) {
         if constexpr (POP) {
             unsigned long long fresh;
-            pol = L.turnover_group(a, task, wrap, pol, &fresh);
+            pol = L.turnover_group(a, task, wrap, pol, &fresh, fault);
             if (fresh) {  // only this wave reads or writes its images, in program order
                 while (fresh) {
                     const int first = __ffsll((long long)fresh) - 1;

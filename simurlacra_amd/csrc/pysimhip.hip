@@ -40,6 +40,10 @@ static __device__ __align__(256) unsigned char scratch[PSH_STATIC_BYTES];
 
 static std::mutex g_scratch_lock;
 static unsigned char* g_scratch_ptr[64];  // per HIP device, filled with that device current
+// The array is shared by every context on a device, so the calls that use it are ordered per DEVICE: each waits for the
+// event recorded behind the previous one, whatever context or stream issued that.
+static hipEvent_t g_static_done[64];
+static bool g_static_have_done[64];
 
 static int static_scratch_of(psh_ctx* c) {
     if (c->device < 0 || c->device >= 64) return PSH_ERR_NODEV;
@@ -47,6 +51,7 @@ static int static_scratch_of(psh_ctx* c) {
     if (!g_scratch_ptr[c->device]) {
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PSH_ERR_HIP;
+        if (hipEventCreateWithFlags(&g_static_done[c->device], hipEventDisableTiming) != hipSuccess) return PSH_ERR_HIP;
         g_scratch_ptr[c->device] = static_cast<unsigned char*>(p);
     }
     c->static_scratch = g_scratch_ptr[c->device];
@@ -372,7 +377,10 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     for (int j = 0; j < PSH_TANH8_N; ++j) tab[j] = (double)tanhl((long double)j / 256.0L);
     for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
     const size_t tab_bytes = tab_n * sizeof(double);
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+    bool events_ok = true;
+    for (int j = 0; j < PSH_TIMING_RING; ++j)
+        events_ok = events_ok && hipEventCreate(&c->tev0[j]) == hipSuccess && hipEventCreate(&c->tev1[j]) == hipSuccess;
+    if (!events_ok ||
         hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess || static_scratch_of(c) != PSH_OK ||
         hipMalloc(&c->queue, 256) != hipSuccess || hipMalloc(&c->tanh_tab, tab_bytes) != hipSuccess ||
         hipMemcpy(c->tanh_tab, tab.get(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -392,8 +400,10 @@ extern "C" void psh_destroy(psh_ctx* c) {
     if (c->delay_q) (void)hipFree(c->delay_q);
     if (c->queue) (void)hipFree(c->queue);
     if (c->tanh_tab) (void)hipFree(c->tanh_tab);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int j = 0; j < PSH_TIMING_RING; ++j) {
+        if (c->tev0[j]) (void)hipEventDestroy(c->tev0[j]);
+        if (c->tev1[j]) (void)hipEventDestroy(c->tev1[j]);
+    }
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     delete c;
 }
@@ -428,7 +438,6 @@ static int rollout_issue(psh_ctx* c, const psh_rollout_desc* d, hipStream_t st) 
     a.task = d->task; a.wrap = d->wrap; a.pol = d->policy; a.bernoulli = d->bernoulli_reset;
     a.ret = d->ret; a.length = d->length; a.status = d->status; a.final_state = d->final_state;
     a.obs = d->obs; a.act = d->act; a.rew = d->rew;
-    c->timed = 1;
     a.queue = c->static_mode ? reinterpret_cast<unsigned int*>(c->static_scratch) : c->queue;
     PSH_HIP(c, hipMemsetAsync(a.queue, 0, PSH_STATIC_QUEUE_BYTES, st));
     if (d->env_kind == PSH_ENV_QBB && !(d->flags & PSH_F_SIMPLIFIED_DYN)) {
@@ -477,13 +486,39 @@ static int rollout_checked(psh_ctx* c, const psh_rollout_desc* d, bool use_stati
     if (rc != PSH_OK) return rc;
     PSH_HIP(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)d->stream;
-    // one rollout of a context at a time: its scratch is shared, so a launch on another stream waits for the last one
-    if (c->have_done) PSH_HIP(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    // A stream that is being captured into a graph takes the kernels and the memset only: events recorded outside the
+    // capture cannot be waited for inside it, and events recorded inside it cannot be synchronised with afterwards.  The
+    // caller then orders the replays against other rollouts that use the same scratch.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    // one rollout per scratch at a time: a launch on another stream waits for the last one that used the same scratch --
+    // the context's, or (psh_rollout_static) the device's static array, which all contexts of a device share
+    hipEvent_t done = c->ev_done;
+    bool have = c->have_done != 0;
+    if (use_static) {
+        std::lock_guard<std::mutex> guard(g_scratch_lock);
+        done = g_static_done[c->device];
+        have = g_static_have_done[c->device];
+    }
+    if (have && !capturing) PSH_HIP(c, hipStreamWaitEvent(st, done, 0));
     c->static_mode = use_static ? 1 : 0;
+    c->timed = capturing ? 0 : 1;
+    const int slot = (int)(c->n_timed % PSH_TIMING_RING);
+    c->ev0 = c->tev0[slot];
+    c->ev1 = c->tev1[slot];
     rc = rollout_issue(c, d, st);
+    if (rc == PSH_OK && c->timed) c->n_timed += 1;
     c->static_mode = 0;
     // recorded also after a failure: whatever was enqueued before it (memset, prologue) may still touch the scratch
-    if (hipEventRecord(c->ev_done, st) == hipSuccess) c->have_done = 1;
+    if (!capturing && hipEventRecord(done, st) == hipSuccess) {
+        if (use_static) {
+            std::lock_guard<std::mutex> guard(g_scratch_lock);
+            g_static_have_done[c->device] = true;
+        } else {
+            c->have_done = 1;
+        }
+    }
     return rc;
 }
 
@@ -491,13 +526,18 @@ extern "C" int psh_rollout(psh_ctx* c, const psh_rollout_desc* d) { return rollo
 
 extern "C" int psh_rollout_static(psh_ctx* c, const psh_rollout_desc* d) { return rollout_checked(c, d, true); }
 
-extern "C" float psh_last_rollout_ms(psh_ctx* c) {
-    if (!c || !c->timed) return -1.f;
-    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+extern "C" float psh_rollout_ms(psh_ctx* c, int32_t back) {
+    if (!c || back < 0 || back >= PSH_TIMING_RING || (long)back >= c->n_timed) return -1.f;
+    const int slot = (int)((c->n_timed - 1 - back) % PSH_TIMING_RING);
+    if (hipEventSynchronize(c->tev1[slot]) != hipSuccess) return -1.f;
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, c->tev0[slot], c->tev1[slot]) != hipSuccess) return -1.f;
     return ms;
 }
+
+extern "C" float psh_last_rollout_ms(psh_ctx* c) { return psh_rollout_ms(c, 0); }
+
+extern "C" int64_t psh_alloc_count(const psh_ctx* c) { return c ? (int64_t)c->n_allocs : -1; }
 
 static int fill_step_args(psh_ctx* c, const psh_step_desc* d, StepArgs& a, int32_t dm[5], bool is_reset) {
     if (!c || !d) return PSH_ERR_ARG;

@@ -119,7 +119,7 @@ class Engine:
         dev = self.device
         if out is None:
             out = dict(ret=torch.empty(N, dtype=torch.float64, device=dev),
-                       length=torch.empty(N, dtype=torch.int32, device=dev),
+                       length=torch.full((N,), -1, dtype=torch.int32, device=dev),   # -1: never stored
                        status=torch.empty(N, dtype=torch.int32, device=dev))
             if final_state:
                 out['final_state'] = torch.empty((S, N), dtype=torch.float64, device=dev)
@@ -153,6 +153,14 @@ class Engine:
 
     def last_rollout_ms(self) -> float:
         return float(self.lib.psh_last_rollout_ms(self._h))
+
+    def rollout_ms(self, back: int = 0) -> float:
+        """ Kernel time (HIP events on the launch stream) of the rollout issued `back` launches before the latest one. """
+        return float(self.lib.psh_rollout_ms(self._h, int(back)))
+
+    def alloc_count(self) -> int:
+        """ Device allocations the library has made for this context's scratch buffers. """
+        return int(self.lib.psh_alloc_count(self._h))
 
     # -- single steps
     def _step_desc(self, env_kind, dt, max_steps, task_c, domain_param, flags, dp_index):

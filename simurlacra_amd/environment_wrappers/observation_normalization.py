@@ -57,3 +57,24 @@ class ObsNormWrapper(EnvWrapperObs):
         lb_norm = (lb - lb_ov)/(ub_ov - lb_ov)*2 - 1
         ub_norm = (ub - lb_ov)/(ub_ov - lb_ov)*2 - 1
         return BoxSpace(lb_norm, ub_norm, labels=space.labels)
+
+
+class ObsRunningNormWrapper(EnvWrapperObs):
+    """ Observations mapped to [-1, 1] with the bounds observed so far (observation_normalization.py:109-135;
+    RunningNormalizer, Pyrado/pyrado/utils/normalizing.py:7-84).  Host-only: the normalizer's bounds grow over all
+    rollouts of the object's life, so the wrapper is not local to a lane of the rollout kernels; EnvPlan rejects it and
+    rollout() steps such an environment through psh_step. """
+
+    def __init__(self, wrapped_env):
+        super().__init__(wrapped_env)
+        from ..utils.normalizing import RunningNormalizer
+        self.normalizer = RunningNormalizer()
+
+    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
+        return self.normalizer(obs)
+
+    def _process_obs_space(self, space: BoxSpace) -> BoxSpace:
+        if not isinstance(space, BoxSpace):
+            raise NotImplementedError('Only implemented ObsRunningNormWrapper._process_obs_space() for BoxSpace!')
+        one = np.ones(space.shape)
+        return BoxSpace(-one, one, labels=space.labels)

@@ -463,6 +463,12 @@ class RolloutBatch(Sequence):
     def check(self):
         """ Raise as rollout() does when an observation, action or state became NaN in any lane. """
         st = self._h('status')[self._offset:self._offset + self._count]
+        # results the launch never wrote (Engine.rollout pre-fills the lengths with -1) or wrote under an internal fault
+        lost = np.flatnonzero(self._h('length')[self._offset:self._offset + self._count] < 0)
+        if lost.size:
+            raise RuntimeError(f'the rollout kernel stored no result for {lost.size} rollouts (first: {int(lost[0])})')
+        if np.any(st & abi.ST_INTERNAL):
+            raise RuntimeError(f'the rollout kernel reported an internal fault (status bit {abi.ST_INTERNAL})')
         bad = np.flatnonzero(st & abi.ST_BAD_INDEX)
         if bad.size:
             raise ValueErr(msg=f'Rollout {int(bad[0])} of the batch names a domain-parameter column or a policy outside '
@@ -572,6 +578,8 @@ class GatheredBatch(Sequence):
 
     def check(self):
         st = self._host['status']
+        if np.any(self._host['length'] < 0) or np.any(st & abi.ST_INTERNAL):
+            raise RuntimeError('the rollout kernel of some rank stored no result for a rollout or reported an internal fault')
         bad = np.flatnonzero(st & (abi.ST_BAD_INDEX | abi.ST_NAN))
         if bad.size:
             raise ValueErr(msg=f'At least one value is NaN or an index is outside its table! (rollout {int(bad[0])} of '

@@ -181,3 +181,44 @@ def test_samplers_return_the_same_rollout_lists_on_every_rank():
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] == [] for r in res), [r[:2] for r in res]   # numbers of the failed checks per rank
     assert res[0][2] == res[1][2]
+
+
+# ------------------------------------------------------------------ bench.py --gpus N starts its own ranks
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv), capture_output=True, text=True,
+                          timeout=300, env=e)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """ `bench.py --gpus 2` without a launcher around it: two ranks (gloo, the stub engine whose results are functions of the
+    global env index), one JSON line from rank 0 with n_gpus = rccl_ranks = 2 and the env-steps of BOTH ranks. """
+    import json
+    sets, R, K, T = 2, 100, 3, 600
+    r = _bench('--gpus', '2', '--backend', 'gloo', '--stub-engine', '--steps', str(K), '--warmup', '1', '--sets', str(sets),
+               '--rollouts', str(R))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['steps'] == K and d['scaling'] == 'weak'
+    n = 2*sets*R                                                       # envs of both ranks, lengths g % T + 1
+    total = K*sum(g % T + 1 for g in range(n))
+    assert d['value']*d['ms_per_step']*1e-3*K == pytest.approx(total, rel=1e-9)
+    assert d['roofline']['kernel_launches_timed'] == K
+    assert d['roofline']['env_steps_per_launch'] == sum(g % T + 1 for g in range(n//2))   # rank 0's share
+    assert 'stub' in d['data']
+
+
+def test_bench_fails_loudly_when_the_ranks_do_not_match():
+    # more GPUs asked for than visible (none here, or fewer than 64 anywhere)
+    r = _bench('--gpus', '64', '--steps', '1', '--warmup', '0')
+    assert r.returncode != 0 and 'GPU(s) are visible' in r.stderr
+    # a launcher that started a different number of ranks than --gpus names
+    r = _bench('--gpus', '4', '--backend', 'gloo', '--stub-engine', '--steps', '1', '--warmup', '0', '--sets', '1', '--rollouts', '10',
+               env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr

@@ -536,6 +536,8 @@ def test_populations_of_up_to_8_rollouts_per_policy(eng, orc, kind, R, hidden):
     out = eng.rollout(kind, case['dt'], T, case['task_c'], case['ps'], params, case['init'], case['dp'], **kwr)
     np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
     np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    # every rollout was stored, and no wave saw the lanes of a policy group disagree about their common state
+    assert np.all(out['length'].cpu().numpy() >= 0) and not np.any(out['status'].cpu().numpy() & abi.ST_INTERNAL)
     for k in ('obs', 'act', 'rew', 'ret', 'final_state'):
         assert cases.rel_err(out[k].cpu().numpy(), ref[k]) <= TOL, k
     # another task (its shape is read at run time), large weights, a NaN in one policy: only its rollouts are affected
@@ -550,6 +552,8 @@ def test_populations_of_up_to_8_rollouts_per_policy(eng, orc, kind, R, hidden):
     out = eng.rollout(kind, case['dt'], T, task_c, case['ps'], params, case['init'], case['dp'], **kwr)
     np.testing.assert_array_equal(out['length'].cpu().numpy(), ref['length'])
     np.testing.assert_array_equal(out['status'].cpu().numpy(), ref['status'])
+    # every rollout was stored, and no wave saw the lanes of a policy group disagree about their common state
+    assert np.all(out['length'].cpu().numpy() >= 0) and not np.any(out['status'].cpu().numpy() & abi.ST_INTERNAL)
     ret, ret_ref = out['ret'].cpu().numpy(), ref['ret']
     np.testing.assert_array_equal(np.isnan(ret), np.isnan(ret_ref))
     ok = ~np.isnan(ret_ref)

@@ -511,3 +511,48 @@ def test_bootstrapping():
     assert cit[0] < x.mean() < cit[1]
     with pytest.warns(UserWarning):
         assert bootstrap_ci(np.ones(8), np.mean, num_reps=10, alpha=0.1, ci_sides=2, studentized=True)[1] == [-np.inf, np.inf]
+
+
+def test_downsampling_and_running_norm_wrappers():
+    """ DownsamplingWrapper (Pyrado/pyrado/environment_wrappers/downsampling.py:93-124) and ObsRunningNormWrapper
+    (observation_normalization.py:109-135) on the host: held actions, the observation window that outlives a reset, the
+    'downsampling' domain parameter, the running bounds incl. the widening of collapsed ones; the batched engine
+    refuses both (their state spans rollouts). """
+    import torch
+    from simurlacra_amd.environment_wrappers import DownsamplingWrapper, ObsRunningNormWrapper
+    from simurlacra_amd.sampling.batch import EnvPlan
+    from simurlacra_amd.utils.normalizing import RunningNormalizer
+    sim = OneMassOscillatorSim(dt=0.01, max_steps=20)
+    ds = DownsamplingWrapper(sim, factor=3)
+    acts = [ds._process_act(np.array([float(k)])) for k in range(7)]
+    assert [float(a[0]) for a in acts] == [0., 0., 0., 3., 3., 3., 6.]
+    obs = [ds._process_obs(np.array([float(k), 1.])) for k in range(5)]
+    assert obs[0].tolist() == [0., 1.] and obs[1].tolist() == [0.5, 1.] and obs[4].tolist() == [3., 1.]   # mean of the last 3
+    dp = {}
+    ds._save_domain_param(dp)
+    assert dp['downsampling'] == 3 and ds.domain_param['downsampling'] == 3
+    ds._load_domain_param(dict(downsampling=np.array(2.)))
+    assert ds.factor == 2
+    ds.factor = 4
+    assert [float(ds._process_act(np.array([float(k)]))[0]) for k in range(5)] == [0., 0., 0., 0., 4.]
+    assert np.allclose(ds._process_obs(np.array([9., 1.])), [(3 + 4 + 9)/3., 1.])    # the window kept its first length
+    seeded = DownsamplingWrapper(sim, factor=2, obs_filter_fcn=lambda w: np.max(w, axis=0), init_obs=np.array([5., -5.]))
+    assert seeded._process_obs(np.array([1., 1.])).tolist() == [5., 1.]
+    with pytest.raises(NotImplementedError):
+        EnvPlan(ds)
+    norm = RunningNormalizer()
+    norm(np.array([0., 10.]))
+    out = norm(np.array([2., 20.]))
+    assert out.tolist() == [1., 1.]
+    # the first sample widened the collapsed bounds by eps/2 = 5e-4 on both sides, and that lower bound stays
+    assert np.allclose(norm(np.array([1., 15.])), [1.0005/2.0005*2 - 1, 5.0005/10.0005*2 - 1], rtol=1e-12)
+    with pytest.raises(Exception):
+        norm(np.array([1., 2., 3.]))
+    tn = RunningNormalizer()
+    tn(torch.tensor([[0., 1.], [4., 3.]], dtype=torch.float64))
+    assert torch.equal(tn(torch.tensor([[2., 2.]], dtype=torch.float64)), torch.tensor([[0., 0.]], dtype=torch.float64))
+    rn = ObsRunningNormWrapper(sim)
+    assert rn.obs_space.bound_up.tolist() == [1., 1.] and rn.obs_space.bound_lo.tolist() == [-1., -1.]
+    assert np.allclose(rn._process_obs(np.array([3., 4.])), 0., atol=1e-9)   # one sample: the middle of its widened bounds
+    with pytest.raises(NotImplementedError):
+        EnvPlan(rn)

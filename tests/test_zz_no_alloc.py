@@ -28,9 +28,10 @@ def _both(eng, case, T, n, **kw):
     # rows of a trajectory past its end stay as the caller left them (NaN in `ref`)
     out = {k: torch.full_like(v, float('nan') if v.is_floating_point() else -7) for k, v in ref.items()}
     torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0, allocs0 = torch.cuda.mem_get_info()[0], eng.alloc_count()
     eng.rollout(*args, record=True, out=out, static_scratch=True, **kw)
     torch.cuda.synchronize()
+    assert eng.alloc_count() == allocs0, 'the library allocated scratch during the call'
     assert torch.cuda.mem_get_info()[0] == free0, 'device memory was allocated or freed during the call'
     for k in ref:
         a, b = out[k].cpu().numpy(), ref[k].cpu().numpy()
@@ -84,3 +85,58 @@ def test_static_rollout_rejects_what_does_not_fit(eng):
     out = eng.rollout(kind, case['dt'], 2, case['task_c'], case['ps'], case['params'], init, case['dp'][:, :1],
                       dp_index=torch.zeros(n, dtype=torch.int32, device=eng.device))
     assert int(out['length'].min()) == 2
+
+
+def test_static_rollout_on_a_fresh_context_allocates_nothing(eng):
+    """ A context that has never run psh_rollout owns no scratch buffers at all: the static call must get by without them
+    (the library counts its own hipMalloc calls per context), with the results of psh_rollout on another context. """
+    from simurlacra_amd.engine import Engine
+    kind = abi.ENV_QBB
+    case = cases.make_case(kind, 2000, seed=11, policy='fnn', hidden=(64, 64))
+    fresh = Engine(0)
+    try:
+        assert fresh.alloc_count() == 0
+        init, dp, params = fresh.f64(case['init']), fresh.f64(case['dp']), fresh.f64(case['params'])
+        out = fresh.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, init, dp, static_scratch=True)
+        torch.cuda.synchronize()
+        assert fresh.alloc_count() == 0
+        ref = eng.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, init, dp)
+        for k in ('ret', 'length', 'status', 'final_state'):
+            np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k].cpu().numpy(), err_msg=k)
+        assert np.all(out['length'].cpu().numpy() > 0)
+        # the growing entry point does allocate on that context (weight image, plate angles)
+        fresh.rollout(kind, case['dt'], 30, case['task_c'], case['ps'], params, init, dp)
+        assert fresh.alloc_count() >= 2
+    finally:
+        torch.cuda.synchronize()
+        fresh.close()
+
+
+def test_static_rollout_captured_into_a_graph_and_replayed(eng):
+    """ On a capturing stream the call enqueues its memset and kernels only; the graph is replayed on new inputs written
+    into the captured buffers and gives the results of psh_rollout on those inputs. """
+    kind, n, T = abi.ENV_QQ, 4096, 50
+    case = cases.make_case(kind, 2*n, seed=13, policy='fnn', hidden=(64, 64))
+    params = eng.f64(case['params'])
+    init, dp = eng.f64(case['init'][:, :n]), eng.f64(case['dp'][:, :n])
+    args = (kind, case['dt'], T, case['task_c'], case['ps'], params)
+    out = eng.rollout(*args, init, dp, static_scratch=True)   # warm-up outside the capture (module load, attributes)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=eng.device)
+    allocs0 = eng.alloc_count()
+    with torch.cuda.graph(graph, stream=side):
+        eng.rollout(*args, init, dp, out=out, static_scratch=True)
+    assert eng.alloc_count() == allocs0
+    for half in (0, 1):
+        init.copy_(eng.f64(case['init'][:, half*n:(half + 1)*n]))
+        dp.copy_(eng.f64(case['dp'][:, half*n:(half + 1)*n]))
+        for v in out.values():
+            v.fill_(-3)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy().copy() for k, v in out.items()}
+        ref = eng.rollout(*args, init, dp)
+        for k in got:
+            np.testing.assert_array_equal(got[k], ref[k].cpu().numpy(), err_msg=f'{k} (replay {half})')
+    assert eng.rollout_ms(0) > 0.   # the eager launches are timed; the captured one recorded no events
