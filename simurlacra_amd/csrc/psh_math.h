@@ -120,6 +120,15 @@ PSH_MATH unsigned psh_tanh8_index_bounded(double x, double* d) {
     const unsigned j = (unsigned)__double2loint(jm);
     return j < (unsigned)(PSH_TANH8_N - 1) ? j : (unsigned)(PSH_TANH8_N - 1);
 }
+// The same for an argument known to be FINITE and below 2^40 in magnitude whose table index needs no limit either: either
+// |x| < 20 is known, or the caller limits the index it gets (beyond 20 the split is still exact, node 5120 has T = 1 and
+// the finish step then returns exactly 1: td - T u = 0).
+PSH_MATH unsigned psh_tanh8_index_free(double x, double* d) {
+    const double a = fabs(x);
+    const double jm = a + 26388279066624.0;    // 1.5 * 2^44
+    *d = a - (jm - 26388279066624.0);
+    return (unsigned)__double2loint(jm);
+}
 PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
     const double z = d * d;
     const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;   // 2/15, -1/3; d^7 is below 2^-58

@@ -59,6 +59,10 @@ struct RolloutArgs {
 static_assert(sizeof(psh_task) % 8 == 0 && sizeof(psh_wrappers) % 8 == 0, "staged as doubles");
 static_assert(offsetof(RolloutArgs, wrap) == offsetof(RolloutArgs, task) + sizeof(psh_task), "staged as one block");
 constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
+// Fast activations (see k_rollout_fnn): observations up to FNN_OBS_LIMIT against a first layer whose largest absolute
+// row sum (+ |bias|) stays below FNN_GAIN_LIMIT keep every pre-activation finite and below 2^40, where the table split of
+// the tanh is exact without any clamp.
+constexpr double FNN_OBS_LIMIT = 1048576.0, FNN_GAIN_LIMIT = 524288.0;   // 2^20, 2^19
 constexpr double FNN_BOUND_LIMIT = 19.9;   // k_fnn_bounds: the tanh table ends at 20; the margin covers the rounding of the sums
 constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
 
@@ -712,8 +716,10 @@ template <int N> PSH_DEV void hold_together(double* v) {
 // layer, so a NaN in any of them has to end up in the action.  The table tanh loses NaNs (its clamp works on
 // the high word), so the largest |y| high word of the layer is tracked (one 32-bit max per element) and a NaN is put
 // back into y[0] once per layer.
-// BOUNDED: every |y| is known to stay below 20 (see FNN_BOUND_LIMIT): the cheaper index step without clamp.
-template <int N, bool FINE, bool BOUNDED = false> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
+// BOUNDED = 1: every y is known to be finite and below 2^40 in magnitude (the caller has checked what feeds the layer):
+// no clamp of |y| and no NaN bookkeeping, only the table index is limited.  BOUNDED = 2: every |y| is known to stay
+// below 20 as well (see FNN_BOUND_LIMIT): the index needs no limit either.
+template <int N, bool FINE, int BOUNDED = 0> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
         unsigned hi_max = 0;
         if (FINE && BOUNDED) {
@@ -722,7 +728,8 @@ template <int N, bool FINE, bool BOUNDED = false> PSH_DEV void nl_apply_all(int 
             for (int m0 = 0; m0 < N; m0 += CH) {
                 double d[CH], T[CH];
 #pragma unroll
-                for (int m = 0; m < CH; ++m) T[m] = tanh_tab[psh_tanh8_index_bounded(y[m0 + m], &d[m])];
+                for (int m = 0; m < CH; ++m)
+                    T[m] = tanh_tab[BOUNDED == 2 ? psh_tanh8_index_free(y[m0 + m], &d[m]) : psh_tanh8_index_bounded(y[m0 + m], &d[m])];
 #pragma unroll
                 for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish(y[m0 + m], d[m], T[m]);
             }
@@ -860,6 +867,8 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     int bounded_layers = 0;
     if constexpr (!POP) {
         for (int l = 1; l < n_hidden; ++l) bounded_layers |= (w_lds[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT ? 1 : 0) << l;
+        // bit 0: every weight of the hidden layers is finite and the first layer's gain is moderate (k_fnn_bounds)
+        bounded_layers |= w_lds[a.lds_doubles - 4] <= FNN_GAIN_LIMIT ? 1 : 0;
         bounded_layers = __builtin_amdgcn_readfirstlane(bounded_layers);
     }
     for (;;) {
@@ -935,6 +944,17 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
         for (int r = 0; r < E::A; ++r) act[r] = 0.;  // lanes of skipped tiles get no action
         if (L.live) L.pre_policy(a, wrap, obs);
         if (!__any(L.live)) continue;
+        // Fast activations: a NaN or an infinity can enter a pre-activation only through an observation or a weight.  While
+        // every observation of the wave is finite and moderate (lanes without an environment hold zeros) and the policy's
+        // weights are (checked once, when they were packed), the activations run without clamp and NaN bookkeeping; any
+        // other step takes the careful forms.
+        bool obs_ok = true;
+        if constexpr (TANH && FINE) {
+            bool big = false;
+#pragma unroll
+            for (int r = 0; r < E::O; ++r) big = big || !(fabs(obs[r]) < FNN_OBS_LIMIT);
+            obs_ok = !__any(big);
+        }
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
 #pragma unroll
         for (int r = 0; r < OP; ++r) stage[r * 64 + lane] = obs[r];
@@ -950,6 +970,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
             // are left, then costs a quarter per step; population tasks with fewer than 64 rollouts)
             if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) return;
             const double* const wimg = POP ? w_lds + (tile >> pop_shift) * a.lds_doubles : w_lds;  // of this tile's policy
+            const bool fast = TANH && FINE && obs_ok && (POP ? wimg[a.lds_doubles - 4] <= FNN_GAIN_LIMIT : (bounded_layers & 1) != 0);
             double y[KS];
             // layer 0
             {
@@ -977,7 +998,10 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
+                if (fast)
+                    nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
+                else
+                    nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
             }
             // further hidden layers
             int off = HT * K0 * 64 + REM * HP + HP;
@@ -1002,10 +1026,12 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 for (int t = 0; t < HT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[t][r];
-                if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT)
-                    nl_apply_all<KS, FINE, true>((int)PSH_NL_TANH, y, tanh_tab);
-                else
+                if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
+                    if (fast) nl_apply_all<KS, FINE, 2>((int)PSH_NL_TANH, y, tanh_tab);
+                    else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
+                } else {
                     nl_apply_all<KS, FINE>((int)PSH_NL_TANH, y, tanh_tab);
+                }
                 off += HP;
             }
             for (int l = 1; !WREG && l < n_hidden; ++l) {
@@ -1038,10 +1064,12 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 // behind a tanh layer the inputs lie in [-1, 1]: if the weights of this layer keep every pre-activation
                 // below the table's end (row sums of |W| plus |b|, computed by k_fnn_bounds), the clamp and the NaN
                 // bookkeeping of the activation are not needed
-                if (TANH && FINE && (POP ? wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0))
-                    nl_apply_all<KS, FINE, true>((int)PSH_NL_TANH, y, tanh_tab);
-                else
+                if (TANH && FINE && (POP ? wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0)) {
+                    if (fast) nl_apply_all<KS, FINE, 2>((int)PSH_NL_TANH, y, tanh_tab);
+                    else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
+                } else {
                     nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
+                }
                 off += HT * KS * 64 + HP;
             }
             // output layer on the vector ALU: each lane sums its 16 hidden rows, then the 4 lane groups are added.  The
@@ -1058,8 +1086,10 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 double p = 0.;
 #pragma unroll
                 for (int m = 0; m < KS; ++m) p += wv[m] * y[m];
-                p = sum_over_lane_groups(p);
-                p += wo[E::A * HP + r];
+                // bias + the partial sums of the 4 lane groups: one 4x4x4 MFMA with an all-ones A operand.  Block b of it adds
+                // the B values of the lanes 16 k + 4 b + j over k and hands the sum to all four of them (16 cycles, against
+                // four row swaps, their register copies and two additions).
+                p = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, p, wo[E::A * HP + r], 0, 0, 0);
                 if (q == tile) act[r] = p;
             }
         };
@@ -1075,6 +1105,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 if (((live_mask >> (16 * p)) & 0xFFFFull) == 0) return;
                 constexpr int NG = WREG == 4 ? 1 : 2;   // column groups of 4 rollouts
                 const double* const wimg = w_lds + p * a.lds_doubles;
+                const bool fast = obs_ok && wimg[a.lds_doubles - 4] <= FNN_GAIN_LIMIT;
                 const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
                 const int unit = 4 * b + h;          // + 16 rs
                 const int env_lane = 16 * p + l;     // + 4 g
@@ -1109,8 +1140,13 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                             y[g][rs] = acc;
                         }
                     }
+                    if (fast) {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    }
                 }
                 int off = HT * K0 * 64 + REM * HP + HP;
                 {
@@ -1146,8 +1182,13 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
 #pragma unroll
                         for (int rs = 0; rs < HT; ++rs) y[g][rs] = acc[rs][g];
                     if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
+                        if (fast) {
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, true>((int)PSH_NL_TANH, y[g], tanh_tab);
+                            for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, 2>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        }
                     } else {
 #pragma unroll
                         for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
@@ -1171,7 +1212,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                         for (int rs = 0; rs < HT; ++rs) s += wv[rs] * y[g][rs];
                         s += rotate_in_row<4>(s);
                         s += rotate_in_row<8>(s);
-                        pg[g] = sum_over_lane_groups(s) + bo;
+                        pg[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, s, bo, 0, 0, 0);   // + the other three rows of 16 lanes
                     }
                     if (h == p && b < NG) act[r] = b == 0 ? pg[0] : pg[NG - 1];
                 }
@@ -1201,9 +1242,10 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
 }
 
 // Largest pre-activation a hidden layer behind a bounded layer can produce: max over its units of sum_i |W[u][i]| + |b[u]|
-// (inputs in [-1, 1]).  Written behind the packed image, one double per layer (entry 0, the input layer, is infinite:
-// observations are not bounded).  A NaN or infinite weight yields a NaN or infinite bound, which fails the kernel's
-// comparison and keeps the clamping activation.  One wave per policy.
+// (inputs in [-1, 1]).  Written behind the packed image, one double per layer.  A NaN or infinite weight yields an
+// infinite bound, which fails the kernel's comparison and keeps the clamping activation.  Entry 0 is the same sum for the
+// input layer (its bound per unit of the largest observation), made infinite when any hidden layer holds a weight that is
+// not finite: the kernels take it as "a NaN or infinity can only come in through an observation".  One wave per policy.
 static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restrict__ params, double* __restrict__ out, int total, int O,
                                                    int A, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
     params += (long)blockIdx.x * num_param;
@@ -1211,6 +1253,8 @@ static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restri
     const int hs[4] = {h0, h1, h2, h3};
     const int u = threadIdx.x;
     int poff = 0, last = O;
+    double first = 0.;
+    bool all_finite = true;
     for (int l = 0; l < 4; ++l) {
         double bound = 0.;
         if (l < n_hidden) {
@@ -1219,21 +1263,24 @@ static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restri
                 for (int i = 0; i < last; ++i) bound += fabs(params[poff + u * last + i]);
                 bound += fabs(params[poff + h * last + u]);
             }
-            bool bad = bound != bound;
+            bool bad = !(bound < __builtin_inf());
             for (int o = 32; o > 0; o >>= 1) {
                 const double other = __shfl_xor(bound, o);
-                bad = bad || (other != other);
                 bound = other > bound ? other : bound;
             }
             bad = __any(bad);
-            if (bad || l == 0) bound = __builtin_inf();
+            if (bad) bound = __builtin_inf();
+            all_finite = all_finite && !bad;
+            if (l == 0) first = bound;
             poff += h * last + h;
             last = h;
         } else {
             bound = __builtin_inf();
         }
-        if (u == 0) out[l] = bound;
+        if (u == 0 && l > 0) out[l] = bound;
     }
+    // entry 0: the first layer's bound per unit of observation, infinite unless EVERY hidden layer's weights are finite
+    if (u == 0) out[0] = all_finite ? first : __builtin_inf();
 }
 
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
