@@ -813,6 +813,8 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     // less than under the default oldest-first issue (1.2-1.6 % of the launch; any other assignment of the three
     // levels gains less, a fixed priority per wave nothing).
     constexpr int PRIO_MFMA = 0, PRIO_ACT = 2, PRIO_ENV = 3;
+    // TAIL: the single-policy all-tanh kernels run a tile that holds at most 8 environments on 4x4x4 MFMAs (run_tail)
+    constexpr bool TAIL = !POP && TANH && FINE && WREG == 0;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -929,7 +931,11 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 int tiles = 0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) tiles += ((busy >> (16 * t)) & 0xFFFFull) != 0;
-                if ((n_busy + 15) / 16 < tiles) {
+                // (TAIL, below: a last tile with at most 8 environments runs them in column groups of 4, which have to be its
+                // first lanes -- the wave is then kept packed whenever a lane has left)
+                const int rest = n_busy & 15;
+                const bool pack = TAIL && rest >= 1 && rest <= 8 && busy != (n_busy == 64 ? ~0ull : (1ull << n_busy) - 1ull);
+                if ((n_busy + 15) / 16 < tiles || pack) {
                     const unsigned long long idle = ~busy;
                     const int rank_busy = __builtin_amdgcn_mbcnt_hi((unsigned)(busy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)busy, 0u));
                     const int rank_idle = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
@@ -1093,6 +1099,139 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 if (q == tile) act[r] = p;
             }
         };
+        // The end of a launch: the queue is empty, the wave's environments are packed into its first lanes, and the last
+        // tile that holds any has 1..8 of them left.  Such a tile runs on v_mfma_f64_4x4x4_4b_f64 in NG = 1 or 2 column groups of 4
+        // environments -- a quarter or half of the MFMA time and of the activations of a 16-column tile -- from the SAME
+        // packed image in LDS: lane 16 h + 4 b + l of a 16x16x4 fragment (t, s) holds W[16 t + 4 b + l][4 s + h], which is
+        // A_b[i = l][k = h] of block b for the hidden units 16 t + 4 b + (0..3).  All four blocks take the same 4
+        // environments 16 p + 4 g + (0..3) as their columns; lane (h, b, l) receives unit 16 t + 4 b + h of environment l.
+        // BIT FOR BIT the numbers of run_tile: the two MFMA shapes round alike (tools/ubench_mfma_equal.hip), every block
+        // goes through the k-steps in run_tile's order -- as the B operand of k-step ks every block needs the units
+        // 4 ks + h, which block ks % 4 holds: a broadcast of that block's lanes through ds_bpermute -- and the output layer
+        // adds its 16 products per lane group in run_tile's order, the running sum handed from block to block.  So which
+        // path evaluates a step has no influence on an environment's results, and those do not depend on the schedule.
+        // The whole launch ends 1-2 % earlier with it (tools/tail_model.py gran=4 on the benchmark's episode lengths).
+        auto run_tail = [&](const int p, auto ngc) {
+            if constexpr (TAIL) {
+                constexpr int NG = decltype(ngc)::value;
+                const double* const wimg = w_lds;
+                const bool fast = obs_ok && (bounded_layers & 1) != 0;
+                const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
+                const int unit = 4 * b + h;          // + 16 rs
+                const int env_lane = 16 * p + l;     // + 4 g
+                double y[NG][HT];
+                {
+                    double xin[K0 > 0 ? K0 : 1][NG], xr[REM > 0 ? REM : 1][NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                        for (int s = 0; s < K0; ++s) xin[s][g] = stage[(4 * s + h) * 64 + env_lane + 4 * g];
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) xr[j][g] = stage[(4 * K0 + j) * 64 + env_lane + 4 * g];
+                    }
+                    const double* wl = wimg;
+                    const double* wrem = wimg + HT * K0 * 64;
+                    const double* bl = wrem + REM * HP;
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) {
+                        const double bias = bl[16 * rs + unit];
+                        double wj[REM > 0 ? REM : 1], wa[K0 > 0 ? K0 : 1];
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) wj[j] = wrem[j * HP + 16 * rs + unit];
+#pragma unroll
+                        for (int s = 0; s < K0; ++s) wa[s] = wl[(rs * K0 + s) * 64 + lane];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            double acc = bias;
+#pragma unroll
+                            for (int j = 0; j < REM; ++j) acc = fma(wj[j], xr[j][g], acc);
+#pragma unroll
+                            for (int s = 0; s < K0; ++s) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s], xin[s][g], acc, 0, 0, 0);
+                            y[g][rs] = acc;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (fast) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        else nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    }
+                }
+                int off = HT * K0 * 64 + REM * HP + HP;
+                const int row_lane = (lane & 0x33) << 2;   // byte address (ds_bpermute) of lane (h, block 0, l)
+                for (int ly = 1; ly < n_hidden; ++ly) {
+                    const double* wl = wimg + off;
+                    const double* bl = wl + HT * KS * 64;
+                    double acc[HT][NG];
+#pragma unroll
+                    for (int rt = 0; rt < HT; ++rt) {
+                        const double bias = bl[16 * rt + unit];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[rt][g] = bias;
+                    }
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) {
+                        // the units 16 rs + 4 c + h of block c, for every block: the B operands of the k-steps 4 rs + c
+                        double xb[4][NG];
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const int lo = __builtin_amdgcn_ds_bpermute(row_lane + 16 * c4, __double2loint(y[g][rs]));
+                                const int hi = __builtin_amdgcn_ds_bpermute(row_lane + 16 * c4, __double2hiint(y[g][rs]));
+                                xb[c4][g] = __hiloint2double(hi, lo);
+                            }
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                            for (int rt = 0; rt < HT; ++rt) {
+                                const double wf = wl[(rt * KS + 4 * rs + c4) * 64 + lane];
+#pragma unroll
+                                for (int g = 0; g < NG; ++g)
+                                    acc[rt][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(wf, xb[c4][g], acc[rt][g], 0, 0, 0);
+                            }
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int rt = 0; rt < HT; ++rt) y[g][rt] = acc[rt][g];
+                    const bool bounded = ((bounded_layers >> ly) & 1) != 0;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (bounded && fast) nl_apply_all<HT, FINE, 2>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        else if (bounded) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        else nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
+                    }
+                    off += HT * KS * 64 + HP;
+                }
+                // Output layer.  run_tile's lane group q adds the products of its 16 units 16 t + 4 r + q in the order (t, r);
+                // here that is group h, and unit (t, r) sits in block r: the running sum goes round the blocks, one rotation
+                // of the row per term (a lane that is not the term's block computes something nobody reads), and ends in
+                // block 0.  Then the four groups as in run_tile.
+                const double* wo = wimg + off;
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) {
+                    double wv[HT];
+#pragma unroll
+                    for (int rs = 0; rs < HT; ++rs) wv[rs] = wo[r * HP + 16 * rs + unit];
+                    const double bo = wo[E::A * HP + r];
+                    double pg[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        double sm = 0.;
+#pragma unroll
+                        for (int rs = 0; rs < HT; ++rs)
+#pragma unroll
+                            for (int c4 = 0; c4 < 4; ++c4) {
+                                sm = fma(wv[rs], y[g][rs], sm);     // valid in block c4
+                                sm = rotate_in_row<4>(sm);           // block c4 + 1 takes it over
+                            }
+                        pg[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, sm, bo, 0, 0, 0);   // (block 0 holds the sums)
+                    }
+                    if (NG == 2) pg[NG - 1] = rotate_in_row<4>(pg[NG - 1]);   // to block 1, whose lanes run column group 1
+                    if (h == p && b < NG) act[r] = b == 0 ? pg[0] : pg[NG - 1];
+                }
+            }
+        };
         // WREG = 3: the policy forward of the up to 8 environments in the first 8 lanes of tile p, on 4x4x4 MFMAs.
         // Lane (h, b, l) = 16 h + 4 b + l supplies A_b[i = l][k = h] and B_b[k = h][j = l] of block b and receives
         // D_b[i = h][j = l].  Block b takes the hidden units 16 rs + 4 b + (0..3) of row step rs, all blocks the same 4
@@ -1225,7 +1364,15 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
             run_tile(0, wreg[0]);
             run_tile(1, wreg[1]);
         } else {
-            for (int tile = 0; tile < 4; ++tile) run_tile(tile, wreg[0]);
+            for (int tile = 0; tile < 4; ++tile) {
+                if constexpr (TAIL) {
+                    // (only a draining wave has its environments packed, so only then can a tile hold few of them in its first lanes)
+                    const unsigned in_tile = (unsigned)(live_mask >> (16 * tile)) & 0xFFFFu;
+                    if (in_tile != 0 && (in_tile & 0xFFF0u) == 0) { run_tail(tile, std::integral_constant<int, 1>{}); continue; }
+                    if (in_tile != 0 && (in_tile & 0xFF00u) == 0) { run_tail(tile, std::integral_constant<int, 2>{}); continue; }
+                }
+                run_tile(tile, wreg[0]);
+            }
         }
         __builtin_amdgcn_s_setprio(PRIO_ENV);
         // output nonlinearity, once per lane on its own action.  A branch the compiler must keep: without side

@@ -3,7 +3,9 @@ how much of the launch is the drain after the queue has run empty, and what hand
 to other waves would recover.  Until the queue is empty the waves step in lock-step rounds; the drain is simulated
 per SIMD (event driven): a round of a SIMD costs the sum over its waves of E + tiles*TT clocks
 (E: the per-wave part of a step, TT: one 16-env tile through the network).
-Usage: python tools/tail_model.py [lengths.npy] [donate_at_most ...] """
+Usage: python tools/tail_model.py [lengths.npy] [donate_at_most ...] [gran=G]
+gran=G: a draining wave pays for its busy lanes in units of G lanes (16: whole MFMA tiles; 4 or 8: column groups of the
+4x4x4 MFMA form of the network, at G/16 of a tile's cost each). """
 import heapq
 import sys
 
@@ -14,6 +16,8 @@ CUS, WAVES, SIMDS = 256, 12, 4
 CLK = 2.4e9
 
 args = sys.argv[1:]
+GRAN = next((int(x[5:]) for x in args if x.startswith('gran=')), 16)
+args = [x for x in args if not x.startswith('gran=')]
 path = args[0] if args and args[0].endswith('.npy') else 'gpurun_out/lengths.npy'
 thresholds = [int(x) for x in args if not x.endswith('.npy')] or [0, 16, 32, 48]
 ln = np.load(path).astype(np.int64)
@@ -74,7 +78,7 @@ def drain(res0, donate_at_most, per_alive=16):
                     alive[w] = False
                     n_alive -= 1
                 continue
-            cost += E + -(-len(r)//16)*TT
+            cost += E + -(-len(r)//GRAN)*(TT*GRAN/16.)
             res[w] = [x - 1 for x in r if x > 1]
         if cost > 0. or any(alive[w] for w in simd_waves[j]):
             if cost == 0.:
@@ -86,5 +90,5 @@ def drain(res0, donate_at_most, per_alive=16):
 
 for th in thresholds:
     end, moved = drain(res, th)
-    print(f'donate when <= {th:2d} busy: total {end/CLK*1e3:7.2f} ms, loss {100*(end/ideal - 1):5.2f} %, '
+    print(f'gran {GRAN:2d}, donate when <= {th:2d} busy: total {end/CLK*1e3:7.2f} ms, loss {100*(end/ideal - 1):5.2f} %, '
           f'{moved} environments moved')
