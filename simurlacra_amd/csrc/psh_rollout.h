@@ -797,11 +797,15 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // The layers run on v_mfma_f64_4x4x4_4b_f64 instead: four independent 4 x 4 x 4 blocks per instruction at the same
 // rate per multiply-add (16 cycles), here four groups of 4 hidden units against the same 4 rollouts, so a layer costs
 // two column groups of 4 instead of one of 16 -- half the MFMA time and half the activations.  WREG = 4: one column
-// group, for up to 4 rollouts per policy.  The 32-wide networks (16 fragments, 32 registers per policy) run WREG = 2 and 3
+// group, for up to 4 rollouts per policy.  WREG = 5: as WREG = 3 with ONE policy per wave and two waves per SIMD (workgroups
+// of 8 waves, 256 registers each, 128 of them the policy's): the same number of policies per SIMD, but two instruction
+// streams -- a wave alone on its SIMD runs at the latency of its dependent chains (environment step, activations) and
+// leaves the pipe half idle.  WREG = 6: the same with one column group (up to 4 rollouts), WREG = 7: the same with a 16-column
+// tile (up to 16 rollouts per task).  The 32-wide networks (16 fragments, 32 registers per policy) run WREG = 2 and 3
 // with two waves per SIMD: their LDS images of 10 KB each kept only two or three waves of four policies on a CU.
-constexpr int NSET_OF(int wreg) { return wreg >= 2 ? 2 : 1; }
+constexpr int NSET_OF(int wreg) { return wreg >= 2 && wreg <= 4 ? 2 : 1; }
 template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
-__global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
+__global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     static_assert(!WREG || (POP && TANH && FINE && HP >= 32), "WREG is the population kernel of the 32- and 64-wide tanh networks");
     // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
@@ -815,6 +819,8 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     constexpr int PRIO_MFMA = 0, PRIO_ACT = 2, PRIO_ENV = 3;
     // TAIL: the single-policy all-tanh kernels run a tile that holds at most 8 environments on 4x4x4 MFMAs (run_tail)
     constexpr bool TAIL = !POP && TANH && FINE && WREG == 0;
+    // NARROW: the register-weight kernels whose policies run in column groups of 4 rollouts (run_narrow)
+    constexpr bool NARROW = WREG >= 3 && WREG != 7;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
     }
     // WREG = 3: the 4-lane block whose value a rotation by 4 rot lanes within the row of 16 delivers to this lane
     int b_from[4] = {0, 0, 0, 0};
-    if constexpr (WREG >= 3) {
+    if constexpr (NARROW) {
         b_from[0] = (lane >> 2) & 3;
         b_from[1] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 4, 0xf, 0xf, false) >> 2) & 3;
         b_from[2] = (__builtin_amdgcn_update_dpp(0, lane, 0x120 + 8, 0xf, 0xf, false) >> 2) & 3;
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                         for (int j = OFF1 + lane; j < a.lds_doubles; j += 64) dst[j] = src[j + BLOCK];
                         // WREG = 3: register (rs, rp, rot) holds the lane's value of fragment (rs, 4 rp + block the rotation
                         // `rot` of the activations reads from), see run_narrow.  One base per rotation, constant offsets behind it.
-                        if constexpr (WREG >= 3) {
+                        if constexpr (NARROW) {
                             const double* base[4];
 #pragma unroll
                             for (int rot = 0; rot < 4; ++rot) base[rot] = src + OFF1 + b_from[rot] * 64 + lane;
@@ -1240,9 +1246,9 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
         // ks = 4 rp + b, those of the other blocks by rotating the row of 16 lanes by 4, 8 and 12 -- every block goes
         // through the 16 k-steps in an order of its own, which its weight registers follow (frag_of above).
         auto run_narrow = [&](const int p, const double* wr) {
-            if constexpr (WREG >= 3) {
+            if constexpr (NARROW) {
                 if (((live_mask >> (16 * p)) & 0xFFFFull) == 0) return;
-                constexpr int NG = WREG == 4 ? 1 : 2;   // column groups of 4 rollouts
+                constexpr int NG = (WREG == 4 || WREG == 6) ? 1 : 2;   // column groups of 4 rollouts
                 const double* const wimg = w_lds + p * a.lds_doubles;
                 const bool fast = obs_ok && wimg[a.lds_doubles - 4] <= FNN_GAIN_LIMIT;
                 const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
@@ -1357,12 +1363,12 @@ __global__ __launch_bounds__(WREG ? (HP == 64 ? 256 : 512) : ((WRAP || POP) ? 51
                 }
             }
         };
-        if constexpr (WREG >= 3) {   // two policies of up to 8 (WREG = 4: up to 4) rollouts, each with its own register set
+        if constexpr (NARROW) {   // policies of up to 8 (WREG = 4, 6: up to 4) rollouts, each with its own register set
             run_narrow(0, wreg[0]);
-            run_narrow(1, wreg[1]);
-        } else if constexpr (WREG == 2) {   // two tiles, each with the register set of its own policy
+            if constexpr (NSET == 2) run_narrow(1, wreg[NSET - 1]);
+        } else if constexpr (WREG == 2 || WREG == 7) {   // one or two tiles, each with the register set of its own policy
             run_tile(0, wreg[0]);
-            run_tile(1, wreg[1]);
+            if constexpr (NSET == 2) run_tile(1, wreg[NSET - 1]);
         } else {
             for (int tile = 0; tile < 4; ++tile) {
                 if constexpr (TAIL) {
@@ -1726,9 +1732,25 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
 #define PSH_LAUNCH_WREG(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, 256, lds_w, a, E::A, WRAP_ && has_delay, st, lanes)
             const bool fixt = task_has_default_shape<KIND>(d->task);   // the default task shape compiled in
             // (up to 8 rollouts per policy: the layers on 4x4x4 MFMAs, two column groups of 4 instead of a tile of 16)
-            if (two && grp <= 4) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 4, true) : PSH_LAUNCH_WREG(true, 4, false)) : (fixt ? PSH_LAUNCH_WREG(false, 4, true) : PSH_LAUNCH_WREG(false, 4, false));
-            if (two && grp <= 8) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 3, true) : PSH_LAUNCH_WREG(true, 3, false)) : (fixt ? PSH_LAUNCH_WREG(false, 3, true) : PSH_LAUNCH_WREG(false, 3, false));
-            if (two) return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 2, true) : PSH_LAUNCH_WREG(true, 2, false)) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
+            if (two) {
+                // one policy per wave, two waves per SIMD once there are more tasks than SIMDs (WREG = 5, 6, 7):
+                // up to 8 rollouts in two column groups of 4, up to 4 in one, more in tiles of 16
+                const int block5 = tasks16 > 4L * c->num_cus ? 512 : 256;
+                const size_t lds5 = ((block5 / 64) * ((size_t)a.lds_doubles + OP * 64) + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
+                const long lanes5 = tasks16 * 64;
+                a.pop_groups = 1;
+#define PSH_LAUNCH_WREG5(WRAP_, SETS_, FIXT_) launch_persistent(c, k_rollout_fnn<KIND, 64, true, WRAP_, true, true, SETS_, FIXT_>, block5, lds5, a, E::A, WRAP_ && has_delay, st, lanes5)
+#define PSH_LAUNCH_WREG5_ALL(SETS_) (wrapped ? (fixt ? PSH_LAUNCH_WREG5(true, SETS_, true) : PSH_LAUNCH_WREG5(true, SETS_, false)) : (fixt ? PSH_LAUNCH_WREG5(false, SETS_, true) : PSH_LAUNCH_WREG5(false, SETS_, false)))
+                if (grp <= 4) return PSH_LAUNCH_WREG5_ALL(6);
+                if (grp <= 8) return PSH_LAUNCH_WREG5_ALL(5);
+                if (block5 == 512) return PSH_LAUNCH_WREG5_ALL(7);
+#undef PSH_LAUNCH_WREG5_ALL
+#undef PSH_LAUNCH_WREG5
+                // (tiles of 16 with a SIMD for every task: the kernel with all 512 registers of a wave alone on its SIMD is
+                // ahead -- 256 policies x 16 rollouts 3.1 against 3.5 ms)
+                a.pop_groups = per_wave;
+                return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 2, true) : PSH_LAUNCH_WREG(true, 2, false)) : (fixt ? PSH_LAUNCH_WREG(false, 2, true) : PSH_LAUNCH_WREG(false, 2, false));
+            }
             return wrapped ? (fixt ? PSH_LAUNCH_WREG(true, 1, true) : PSH_LAUNCH_WREG(true, 1, false)) : (fixt ? PSH_LAUNCH_WREG(false, 1, true) : PSH_LAUNCH_WREG(false, 1, false));
 #undef PSH_LAUNCH_WREG
         }
