@@ -302,7 +302,8 @@ typedef struct psh_rollout_desc {
     int32_t* status;      /* [N]   PSH_ST_* bits */
     double* final_state;  /* [S, N] ld = N, state after the last executed step */
     double* obs;          /* [T+1, O', N] observations incl. the final one (O' = O, or the kept entries of
-                             OBS_PARTIAL); rows past length+1 untouched.  With PSH_F_TRAJ_ENV_MAJOR the three
+                             OBS_PARTIAL); the rows of a rollout past its end (all three arrays) are either left as the
+                             caller passed them or set to NaN (the LinearPolicy kernels pad whole 128-byte lines).  With PSH_F_TRAJ_ENV_MAJOR the three
                              trajectory arrays are [N, T+1, O'], [N, T, A], [N, T] instead */
     double* act;          /* [T, A, N]   recorded actions (raw policy output; QBB: dead-zoned, see ACT_DELAY) */
     double* rew;          /* [T, N]      step rewards (final reward folded into the last step) */

@@ -5,14 +5,19 @@
  * standalone-Python simulations.  Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of
  * bench.py may load this file's library; the product (simurlacra_amd + libpysimhip.so) never does.
  *
- * PARITY STATUS: the reference's Python could not be executed in the build environment and its own
- * tests hold no numeric vectors for the per-step dynamics of the five simulations, so the dynamics
- * are "parity unpinned": they are pinned only by restating the cited source lines expression by
- * expression (same operand order, no FMA contraction: build with -ffp-contract=off) and by a second,
- * independent NumPy restatement (oracle/pysim_oracle_np.py) that must agree to ~1 ulp.  The parts the
- * reference's tests DO pin with numbers are checked against those numbers in tests/test_oracle.py and tests/test_anchors.py:
- * radial-wrap reward (Pyrado/tests/test_tasks.py:44-61), FinalRewTask yields once (:181-188),
- * polar sampling (Pyrado/tests/test_spaces.py:145-154).
+ * PARITY STATUS: the reference's Python could not be executed in the build environment.
+ *  - OneMassOscillatorSim is pinned by a trajectory the reference itself produced and ships
+ *    (Pyrado/data/perma/time_series/omo_traj_gt.npy, made by Pyrado/scripts/sandbox/time_series/gen_ts_data.py:22-44):
+ *    this file reproduces its 501 samples bit for bit through orc_reset / orc_step and through its rollout loop
+ *    (tests/test_reference_golden.py) -- dynamics, the order of operations of a step, and the rollout loop.
+ *  - For QQube, QCartPole, QBallBalancer and BallOnBeam neither the reference's tests nor its data files hold numbers
+ *    for the per-step dynamics: these are "parity unpinned", pinned only by restating the cited source lines expression
+ *    by expression (same operand order, no FMA contraction: build with -ffp-contract=off), by a second, independent
+ *    NumPy restatement (oracle/pysim_oracle_np.py) that must agree to ~1 ulp, and by hand-computed one-step numbers
+ *    (tests/anchors.py).
+ *  - The parts the reference's tests pin with numbers are checked against those numbers in tests/test_oracle.py and
+ *    tests/test_anchors.py: radial-wrap reward (Pyrado/tests/test_tasks.py:44-61), FinalRewTask yields once (:181-188),
+ *    polar sampling (Pyrado/tests/test_spaces.py:145-154).
  *
  * It reads the same descriptors as the product ABI (include/pysimhip.h) with HOST pointers.
  * Paths below are relative to /root/reference/Pyrado/pyrado/.

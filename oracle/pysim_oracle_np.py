@@ -4,9 +4,12 @@ one environment at a time with NumPy, calling the same NumPy routines the refere
 (np.sin/cos/fmod/exp/log/clip, np.linalg.solve, ndarray.dot).  It exists to cross-check the C
 restatement (oracle/pysim_oracle.c) and to generate the golden vectors under tests/golden/.
 
-PARITY STATUS: "parity unpinned" for the per-step dynamics (the reference could not be executed in the
-build environment and its tests hold no numbers for them); pinned by the reference's own known-answer
-tests for rewards, final rewards and spaces (tests/test_oracle_kat.py).
+PARITY STATUS (the reference could not be executed in the build environment): OneMassOscillatorSim is pinned by the
+trajectory Pyrado/data/perma/time_series/omo_traj_gt.npy that the reference produced (tests/test_reference_golden.py:
+1e-12 here -- this image's BLAS fuses a multiply-add inside ndarray.dot -- and bit for bit in the C restatement);
+"parity unpinned" for the per-step dynamics of QQube, QCartPole, QBallBalancer and BallOnBeam (no numbers for them in
+the reference's tests or data files); pinned by the reference's own known-answer tests for rewards, final rewards and
+spaces (tests/test_oracle.py).
 
 Paths in comments are relative to /root/reference/Pyrado/pyrado/.
 """

@@ -52,6 +52,7 @@ struct RolloutArgs {
     int pop_tiles;           // FNN population mode: MFMA tiles (16 lanes each) per policy task: 1, 2 or 4
     int pop_groups;          // FNN population mode: groups of pop_tiles tiles a wave uses (the lanes beyond stay empty)
     int wave_lanes;          // FNN, one policy: lanes of a wave that take environments (16, 32, 48 or 64; see launch_rollout)
+    int cohort;              // LINEAR, recording: this many adjacent lanes (4, 8, 16 or 32) take consecutive environments together (see Lane::turnover)
 };
 
 // The task description is read from an LDS copy inside the step loop: as kernel arguments its ~90 constants would be
@@ -157,10 +158,11 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     // and again and the launch never ended.  With the flag in a vector register the same build runs to the end.
     int exhausted;
     unsigned int chunk_next, chunk_end;  // wave-uniform: the envs of this wave's current chunk not handed out yet
+    int pad_row;      // cohort mode: the next trajectory row this finished lane pads while its neighbours still run, -1: none yet
     bool rec_alias;   // WRAP: the array the simulation receives is one the rollout has recorded
 
     static constexpr int QUEUE_CHUNK = 8;
-    PSH_DEV void init() { i = -1; live = false; exhausted = 0; chunk_next = chunk_end = 0; }
+    PSH_DEV void init() { i = -1; live = false; exhausted = 0; chunk_next = chunk_end = 0; pad_row = -1; }
 
     // Lanes pull environments from a global queue: a lane whose env is finished stores its results and takes the next
     // unassigned env, so a wave keeps all 64 lanes busy although episodes end at different steps.  Which lane runs
@@ -168,18 +170,30 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     // BATCH > 1: the exchange is deferred until BATCH lanes of the wave wait for it (or none is running any more).
     // Storing and loading an env costs about as much as one step of a LinearPolicy rollout and the whole wave pays
     // for it whenever a single lane needs it; with short episodes that is most steps.
+    // COHORT (a.cohort = 16, launches that record time-major trajectories): the lanes of an aligned group of 16 take 16
+    // consecutive environments together and give them back together, when the last of them has ended.  The group then
+    // stays in lock step, so every trajectory store of it is one whole 128-byte line of a row (a lane whose environment has
+    // ended pads its rows with NaN until the group is done, see pad_rows): environments that end early otherwise leave
+    // their neighbours writing 8- to 120-byte parts of a line, which the memory system turns into read-modify-write
+    // cycles.  Lanes idle for max - own length of their group; what that costs is less than what the partial lines did.
     template <int BATCH = 1> PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
+        const bool cohort = BATCH > 1 && a.cohort != 0;
+        bool octet_done = true;
+        if (cohort) {
+            const int cs = a.cohort;   // 4, 8 or 16 lanes
+            octet_done = ((__ballot(live) >> ((threadIdx.x & 63) & ~(cs - 1))) & ((1ull << cs) - 1ull)) == 0;
+        }
         if (BATCH > 1) {
-            const bool want = (i >= 0 && !live) || (i < 0 && !exhausted);
+            const bool want = (i >= 0 && !live && octet_done) || (i < 0 && !exhausted && octet_done);
             if (__popcll(__ballot(want)) < BATCH && __any(live)) return;
         }
-        if (i >= 0 && !live) { store(a, wrap); i = -1; }
+        if (i >= 0 && !live && octet_done) { store(a, wrap, 0, cohort && pad_row >= 0); i = -1; }
         // The queue is drawn from in chunks of 8 consecutive envs per wave: row r of the inputs of such a chunk is one
         // 64-byte line, fetched once and still in L2 when the wave's next free lane takes the neighbouring env (single
         // envs handed out across all waves cost a line per 8-byte value: 1.8 GB of HBM reads per launch for 0.24 GB of
         // inputs); the 8-byte results of a chunk likewise merge into whole lines.  All lanes of the wave get here
         // together, so the chunk bounds are wave-uniform.
-        bool want = i < 0 && !exhausted, fresh = false;
+        bool want = i < 0 && !exhausted && octet_done, fresh = false;
         unsigned long long m = __ballot(want);
         while (m) {
             if (chunk_next == chunk_end) {
@@ -279,7 +293,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         } else {
             e.reset(init, a.init_dim, false);
         }
-        ret = 0.; curr_step = 0; yielded = 0; k = 0; done = false;
+        ret = 0.; curr_step = 0; yielded = 0; k = 0; done = false; pad_row = -1;
         st = bad_index ? PSH_ST_BAD_INDEX : 0;  // not run: stored with length 0 at the next turnover
         live = a.max_steps > 0 && !bad_index;
         if constexpr (WRAP) {
@@ -470,8 +484,37 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         }
     }
 
-    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap, int extra_status = 0) {
-        if (a.obs) {  // final observation
+    // Cohort mode, a lane whose environment has ended while others of its octet still run: one call per step of the
+    // neighbours writes this environment's share of the rows they write -- its final observation first, NaN afterwards.
+    PSH_DEV void pad_rows(const RolloutArgs& a, const psh_wrappers& wrap) {
+        const double nan = __builtin_nan("");
+        const int Oe = WRAP ? a.obs_dim : E::O;
+        if (pad_row < 0) {
+            pad_row = k;
+            if (a.obs) {
+                double obs[E::O];
+                if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
+#pragma unroll
+                for (int r = 0; r < E::O; ++r)
+                    if (r < Oe) traj_store(a.obs + traj_off(k, r, i, a.obs_sk, a.obs_sr, a.obs_si), obs[r]);
+            }
+        } else if (a.obs) {
+#pragma unroll
+            for (int r = 0; r < E::O; ++r)
+                if (r < Oe) traj_store(a.obs + traj_off(pad_row, r, i, a.obs_sk, a.obs_sr, a.obs_si), nan);
+        }
+        if (pad_row < a.max_steps) {
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(pad_row, r, i, a.act_sk, a.act_sr, a.act_si), nan);
+            }
+            if (a.rew) traj_store(a.rew + traj_off(pad_row, 0, i, a.rew_sk, 0u, a.rew_si), nan);
+        }
+        pad_row += 1;
+    }
+
+    PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap, int extra_status = 0, bool final_obs_written = false) {
+        if (a.obs && !final_obs_written) {  // final observation
             double obs[E::O];
             if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
             const int Oe = WRAP ? a.obs_dim : E::O;
@@ -542,7 +585,10 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
         if (!__all(L.live)) {
             L.template turnover<8>(a, task, wrap);
             if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
-            if (!L.live) continue;        // (a lane without an env is not live)
+            if (!L.live) {                // (a lane without an env is not live)
+                if (a.cohort && L.i >= 0) L.pad_rows(a, wrap);
+                continue;
+            }
             if (PER_ENV && w_env != L.i) {
                 const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
                                                     : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
@@ -1611,6 +1657,10 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         }
         if (p.num_param != E::A * F) { set_err(c, "num_param does not match the LinearPolicy layout"); return PSH_ERR_ARG; }
         a.num_feat = F;
+        // time-major trajectories: octets of lanes in lock step, whole 64-byte pieces per store (Lane::turnover)
+        // (16 lanes = one 128-byte line per row: BallOnBeam, 2^21 rollouts of 69 of 500 steps on average, records in 7.6 ms
+        // with lanes refilled one by one, 6.1 / 4.2 / 3.8 / 3.6 ms in cohorts of 4 / 8 / 16 / 32)
+        a.cohort = (d->obs || d->act || d->rew) && !(a.flags & PSH_F_TRAJ_ENV_MAJOR) ? 16 : 0;
         const bool simple = (p.n_feats == 1 && p.feats[0] == PSH_FEAT_IDENTITY) ||
                             (p.n_feats == 2 && p.feats[0] == PSH_FEAT_CONST && p.feats[1] == PSH_FEAT_IDENTITY);
         // the usual case gets a kernel of its own: bare simulation, const / identity features, the simulation's default task

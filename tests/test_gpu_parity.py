@@ -888,13 +888,15 @@ def test_a_wrapper_list_without_noise_does_not_pay_for_the_noise_draws(eng, kind
     assert t_norm < 1.9*t_bare, (t_bare, t_norm)
 
 
-@pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 300.)], ids=['omo', 'bob'])
+@pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 1200.)], ids=['omo', 'bob'])
 def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, min_gbs):
     """ 2^21 environments with full trajectories (T = 500): OneMassOscillator runs every episode to the end (34 GB of
     trajectory), BallOnBeam ends after 69 steps on average, so every lane is refilled seven times and the wave's lanes
-    sit at different steps of environments from different chunks.  A sample of environments is compared with the
+    takes part in about seven groups of 16 consecutive environments that run in lock step (whole 128-byte lines per store, the
+    rows of an environment that ended before its group padded with NaN).  A sample of environments is compared with the
     oracle step by step; for ALL of them the recorded rewards must add up to the returned return and the rows past an
-    episode's end must be untouched; the writeback rate must stay within reach of what profiles/ records. """
+    episode's end must hold NaN or what the caller passed; the writeback rate must stay within reach of what profiles/
+    records. """
     import torch
     n, T = 1 << 21, 500
     S, O, A, P, I = abi.ENV_DIMS[kind]
@@ -919,8 +921,10 @@ def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, m
     # every environment: rows below its length written, rows above untouched, rewards add up to the return
     k = torch.arange(T, device=dev).unsqueeze(1)
     live = k < length.unsqueeze(0)
-    assert bool(((out['rew'] != marker) == live).all())
-    assert bool(((out['obs'][:, 0, :] != marker) == (torch.arange(T + 1, device=dev).unsqueeze(1) <= length.unsqueeze(0))).all())
+    untouched_or_nan = lambda t: (t == marker) | t.isnan()
+    assert bool((untouched_or_nan(out['rew']) == ~live).all())
+    assert bool((untouched_or_nan(out['obs'][:, 0, :]) == ~(torch.arange(T + 1, device=dev).unsqueeze(1) <= length.unsqueeze(0))).all())
+    assert bool((untouched_or_nan(out['act'][:, 0, :]) == ~live).all())
     total = torch.where(live, out['rew'], torch.zeros((), dtype=torch.float64, device=dev)).sum(dim=0)
     assert float(((total - out['ret']).abs()/out['ret'].abs().clamp(min=1.)).max()) <= 1e-9
     # a sample of environments against the oracle, step by step
@@ -930,7 +934,7 @@ def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, m
     np.testing.assert_array_equal(out['status'][idx].cpu().numpy(), ref['status'])
     for key in ('obs', 'act', 'rew'):
         got = out[key][..., idx].cpu().numpy()
-        got[got == marker] = np.nan
+        got[got == marker] = np.nan   # (padded rows hold NaN already)
         assert cases.rel_err(got, ref[key]) <= TOL, key
     assert cases.rel_err(out['ret'][idx].cpu().numpy(), ref['ret']) <= TOL
     gbs = (steps*(O + A + 1) + n*O)*8/ms/1e6
