@@ -432,7 +432,8 @@ int psh_segment_mean(psh_ctx* ctx, int32_t n_groups, int32_t group_size, const d
 /* Elite selection of the population-based algorithms: indices (and values) of the k largest of n values in descending
  * order, i.e. to.argsort(rets_avg_ros, descending=True)[:num_is_samples] of CEM.update
  * (Pyrado/pyrado/algorithms/cem.py:116-119), argmax of HC (Pyrado/pyrado/algorithms/hc.py:66-82) with k = 1.  Ties are
- * ordered by index; a NaN ranks above every number (as torch sorts it).  Applied to the all-gathered per-policy means
+ * ordered by index; a NaN ranks above every number (as torch sorts it).  O(n^2) comparisons: sized for the up to a few
+ * 10^4 per-policy means of a generation, not for per-rollout arrays.  Applied to the all-gathered per-policy means
  * it keeps the returns on the device between psh_segment_mean and the parameter update. */
 int psh_topk(psh_ctx* ctx, int32_t n, int32_t k, const double* values /*[dev][n]*/, int32_t* idx_out /*[dev][k]*/,
              double* val_out /*[dev][k] or NULL*/, void* stream);

@@ -271,8 +271,9 @@ __global__ __launch_bounds__(256) void k_segment_mean(int n_groups, int group_si
 }
 
 // Descending rank of every value by counting the values ahead of it (greater, or equal with a smaller index; a NaN is
-// ahead of every number).  n threads x n comparisons with the values staged through LDS in tiles: for the population
-// sizes of CEM / NES (up to a few 10^4 per-policy means) that is microseconds, and the order is deterministic.
+// ahead of every number).  n threads x n comparisons with the values staged through LDS in tiles, i.e. O(n^2) work: 10^7
+// comparisons (tens of microseconds) for the 4 096 per-policy means of a CEM / NES generation, 10^9 (milliseconds) at
+// n = 3 x 10^4, which is about where a sort would take over; the order is deterministic.
 __global__ __launch_bounds__(256) void k_topk(int n, int k, const double* __restrict__ v, int* __restrict__ idx_out, double* __restrict__ val_out) {
     __shared__ double tile[256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
