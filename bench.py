@@ -304,10 +304,11 @@ class StubEngine:
 
 def executed_fp64():
     """ Hardware fp64 flop the kernel executes per env-step, from the committed instruction-counter profile of this
-    command (tools/pmc_insts.sh): MFMAs at 2 x 16 x 16 x 4 flop, vector FMA at 2 and MUL / ADD at 1 flop per lane.  (That
-    counter run tallies every instruction twice; its per-wave-step column is halved here.)  Next to the algorithmic
-    `frac` it says how much of the pipe the launch keeps busy with arithmetic of any kind. """
-    for name in ('r03_bench_instruction_mix.txt', 'r02_bench_instruction_mix.txt'):
+    command (tools/pmc_insts.sh): MFMAs at 2 x 16 x 16 x 4 flop (the few 4x4x4 ones of the output layer and of draining waves
+    counted alike: an overestimate of under 2 %), vector FMA at 2 and MUL / ADD at 1 flop per lane.  (The round-2 counter
+    run launched the kernel twice per pass; its per-wave-step column is halved here.)  Next to the algorithmic `frac` it says
+    how much of the pipe the launch keeps busy with arithmetic of any kind. """
+    for name, launches in (('r03_bench_instruction_mix.txt', 1.), ('r02_bench_instruction_mix.txt', 2.)):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -316,7 +317,7 @@ def executed_fp64():
             for line in f:
                 w = line.split()
                 if len(w) >= 5 and w[0].startswith('SQ_') and w[2:4] == ['per', 'wave-step']:
-                    per_ws[w[0]] = float(w[4])/2.
+                    per_ws[w[0]] = float(w[4])/launches
         try:
             flop_ws = (per_ws['SQ_INSTS_MFMA']*2*16*16*4 + 64*(2*per_ws['SQ_INSTS_VALU_FMA_F64'] + per_ws['SQ_INSTS_VALU_MUL_F64']
                                                                + per_ws['SQ_INSTS_VALU_ADD_F64']))
