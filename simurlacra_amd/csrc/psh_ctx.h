@@ -20,7 +20,7 @@ struct psh_ctx {
     double* delay_q;     // ActDelay ring buffers of the resident lanes, grown on demand
     size_t delay_q_doubles;
     unsigned int* queue; // work-queue counter of the rollout kernels
-    double* tanh_tab;    // [tanh(j/256), j = 0..5120 (psh_tanh8)][tanh(j/64), j = 0..1280 (psh_tanh_tab)]
+    double* tanh_tab;    // [tanh(j/256), j = -5120..5120 (the upper half is the table of psh_tanh8)][tanh(j/64), j = 0..1280 (psh_tanh_tab)]
     int num_cus;
     size_t lds_per_block;
     // HIP events around the rollout kernel of the last PSH_TIMING_RING launches (psh_rollout_ms); ev0 / ev1 = the pair of

@@ -129,6 +129,29 @@ PSH_MATH unsigned psh_tanh8_index_free(double x, double* d) {
     *d = a - (jm - 26388279066624.0);
     return (unsigned)__double2loint(jm);
 }
+// Signed form for a table that continues to negative nodes, tanh(j/256) for j = -5120..5120 (`tab` points at node 0):
+// x + 1.5 * 2^44 rounds x itself to a multiple of 1/256, the signed multiple is the low word of the sum in two's
+// complement, and d, T, td keep their signs through the finish step (u = T td and w are even in x, g and T are odd), so
+// neither |x| nor the final sign transfer is needed.  For x > 0 the bits of the unsigned form; for x < 0 its mirror image,
+// except that a tie between two nodes may go to the other one (both are within 2^-9, the results agree to rounding).
+// For finite |x| < 2^40; the caller limits the index to +-5120 unless |x| < 20 is known.
+#define PSH_TANH_ODD_N 10241
+PSH_MATH int psh_tanh8_index_signed(double x, double* d) {
+    const double jm = x + 26388279066624.0;    // 1.5 * 2^44
+    *d = x - (jm - 26388279066624.0);
+    return __double2loint(jm);
+}
+PSH_MATH double psh_tanh8_finish_signed(double d, double T) {
+    const double z = d * d;
+    const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;
+    const double td = fma(p, d, d);
+    const double u = T * td;
+    const double r0 = 1.0 - u;
+    const double e = u * u;
+    const double w = fma(r0, fma(e, e, e), r0);
+    const double g = fma(-T, u, td);
+    return fma(w, g, T);
+}
 PSH_MATH double psh_tanh8_finish(double x, double d, double T) {
     const double z = d * d;
     const double p = fma(z, 1.3333333333333333e-01, -3.3333333333333331e-01) * z;   // 2/15, -1/3; d^7 is below 2^-58

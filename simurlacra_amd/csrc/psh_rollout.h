@@ -65,7 +65,7 @@ constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
 // the tanh is exact without any clamp.
 constexpr double FNN_OBS_LIMIT = 1048576.0, FNN_GAIN_LIMIT = 524288.0;   // 2^20, 2^19
 constexpr double FNN_BOUND_LIMIT = 19.9;   // k_fnn_bounds: the tanh table ends at 20; the margin covers the rounding of the sums
-constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2;
+constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2, TANH_ODD_PAD = (PSH_TANH_ODD_N + 1) / 2 * 2;
 
 // The LDS copy is addressed through a base the compiler has to keep in ONE vector register (it cannot see through the
 // empty asm), so every field is a ds_read with an immediate offset.  Left to itself it materialises one scalar
@@ -764,10 +764,27 @@ template <int N> PSH_DEV void hold_together(double* v) {
 // back into y[0] once per layer.
 // BOUNDED = 1: every y is known to be finite and below 2^40 in magnitude (the caller has checked what feeds the layer):
 // no clamp of |y| and no NaN bookkeeping, only the table index is limited.  BOUNDED = 2: every |y| is known to stay
-// below 20 as well (see FNN_BOUND_LIMIT): the index needs no limit either.
+// below 20 as well (see FNN_BOUND_LIMIT): the index needs no limit either.  BOUNDED = 3, 4: as 1, 2 on a table that
+// continues to negative nodes (`tanh_tab` points at node 0): no |y| and no sign transfer (psh_tanh8_index_signed).
 template <int N, bool FINE, int BOUNDED = 0> PSH_DEV void nl_apply_all(int nl, double* y, const double* tanh_tab) {
     if (nl == PSH_NL_TANH) {
         unsigned hi_max = 0;
+        if (FINE && BOUNDED >= 3) {
+            constexpr int CH = N < 8 ? N : 8;
+#pragma unroll
+            for (int m0 = 0; m0 < N; m0 += CH) {
+                double d[CH], T[CH];
+#pragma unroll
+                for (int m = 0; m < CH; ++m) {
+                    int j = psh_tanh8_index_signed(y[m0 + m], &d[m]);
+                    if (BOUNDED == 3) j = j < -(PSH_TANH8_N - 1) ? -(PSH_TANH8_N - 1) : (j > PSH_TANH8_N - 1 ? PSH_TANH8_N - 1 : j);
+                    T[m] = tanh_tab[j];
+                }
+#pragma unroll
+                for (int m = 0; m < CH; ++m) y[m0 + m] = psh_tanh8_finish_signed(d[m], T[m]);
+            }
+            return;
+        }
         if (FINE && BOUNDED) {
             constexpr int CH = N < 8 ? N : 8;
 #pragma unroll
@@ -850,10 +867,14 @@ template <class T> PSH_DEV void move_lane_state(T& v, int dst) {
 // tile (up to 16 rollouts per task).  The 32-wide networks (16 fragments, 32 registers per policy) run WREG = 2 and 3
 // with two waves per SIMD: their LDS images of 10 KB each kept only two or three waves of four policies on a CU.
 constexpr int NSET_OF(int wreg) { return wreg >= 2 && wreg <= 4 ? 2 : 1; }
-template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false>
+template <int KIND, int HP, bool FINE, bool WRAP, bool POP, bool TANH, int WREG = 0, bool FIXT = false, bool SGN = false>
 __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP || POP) ? 512 : 768)) void k_rollout_fnn(const RolloutArgs a) {
     using E = Env<KIND>;
     static_assert(!WREG || (POP && TANH && FINE && HP >= 32), "WREG is the population kernel of the 32- and 64-wide tanh networks");
+    // SGN: the tanh table in LDS is the odd one, tanh(j/256) for j = -5120..5120 (twice the fine table's LDS): the fast
+    // activations then need neither |y| nor the sign transfer (one vector instruction less each)
+    static_assert(!SGN || (!POP && TANH && FINE), "SGN is a variant of the single-policy all-tanh kernels");
+    constexpr int LV1 = SGN ? 3 : 1, LV2 = SGN ? 4 : 2;   // nl_apply_all levels of the fast activations
     // Layer 0: whole groups of 4 inputs go through the MFMA (K0 k-steps); the REM inputs left over are added on the
     // vector ALU (16 FMAs each per tile) instead of through a k-step that is half zeros (QQube's 6 inputs: 4 + 2)
     constexpr int HT = HP / 16, KS = HP / 4, OP = (E::O + 3) / 4 * 4, K0 = E::O / 4, REM = E::O % 4;
@@ -878,9 +899,11 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
     const int imgs = WREG ? NSET_OF(WREG) : (POP ? a.pop_groups : 1);  // images per wave
     const int w_doubles = POP ? n_waves * imgs * a.lds_doubles : a.lds_doubles;
     double* const w_lds = lds + (POP ? wave * imgs * a.lds_doubles : 0);
-    double* const stage = lds + w_doubles + wave * (OP * 64);
-    double* const tanh_tab = lds + w_doubles + n_waves * (OP * 64);
-    double* const task_lds = tanh_tab + (FINE ? TANH8_PAD : TANH_TAB_PAD);
+    // (a wave's staging area: one row of 64 per observation entry; the rows that pad the observation to a multiple of 4 are never read)
+    double* const stage = lds + w_doubles + wave * (E::O * 64);
+    double* const tanh_lds = lds + w_doubles + n_waves * (E::O * 64);
+    double* const task_lds = tanh_lds + (SGN ? TANH_ODD_PAD : (FINE ? TANH8_PAD : TANH_TAB_PAD));
+    const double* const tanh_tab = tanh_lds + (SGN ? PSH_TANH8_N - 1 : 0);   // node 0
     const double* const task_base = opaque_lds_base(task_lds);
     const psh_task& task = *reinterpret_cast<const psh_task*>(task_base);
     const psh_wrappers& wrap = *reinterpret_cast<const psh_wrappers*>(task_base + sizeof(psh_task) / 8);
@@ -888,7 +911,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
     if constexpr (!POP) {
         for (int j = threadIdx.x; j < w_doubles; j += blockDim.x) w_lds[j] = a.wfrag[j];
     }
-    for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_tab[j] = a.tanh_tab[j];
+    for (int j = threadIdx.x; j < a.tanh_n; j += blockDim.x) tanh_lds[j] = a.tanh_tab[j];
     stage_task(a, task_lds);
     __syncthreads();
 
@@ -1015,7 +1038,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
         }
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
 #pragma unroll
-        for (int r = 0; r < OP; ++r) stage[r * 64 + lane] = obs[r];
+        for (int r = 0; r < E::O; ++r) stage[r * 64 + lane] = obs[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1057,7 +1080,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
                 if (fast)
-                    nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
+                    nl_apply_all<KS, FINE, LV1>((int)PSH_NL_TANH, y, tanh_tab);
                 else
                     nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
             }
@@ -1085,7 +1108,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[t][r];
                 if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
-                    if (fast) nl_apply_all<KS, FINE, 2>((int)PSH_NL_TANH, y, tanh_tab);
+                    if (fast) nl_apply_all<KS, FINE, LV2>((int)PSH_NL_TANH, y, tanh_tab);
                     else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
                 } else {
                     nl_apply_all<KS, FINE>((int)PSH_NL_TANH, y, tanh_tab);
@@ -1123,7 +1146,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                 // below the table's end (row sums of |W| plus |b|, computed by k_fnn_bounds), the clamp and the NaN
                 // bookkeeping of the activation are not needed
                 if (TANH && FINE && (POP ? wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0)) {
-                    if (fast) nl_apply_all<KS, FINE, 2>((int)PSH_NL_TANH, y, tanh_tab);
+                    if (fast) nl_apply_all<KS, FINE, LV2>((int)PSH_NL_TANH, y, tanh_tab);
                     else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
                 } else {
                     nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[l], y, tanh_tab);
@@ -1204,7 +1227,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                     }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        if (fast) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        if (fast) nl_apply_all<HT, FINE, LV1>((int)PSH_NL_TANH, y[g], tanh_tab);
                         else nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
                     }
                 }
@@ -1249,7 +1272,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                     const bool bounded = ((bounded_layers >> ly) & 1) != 0;
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        if (bounded && fast) nl_apply_all<HT, FINE, 2>((int)PSH_NL_TANH, y[g], tanh_tab);
+                        if (bounded && fast) nl_apply_all<HT, FINE, LV2>((int)PSH_NL_TANH, y[g], tanh_tab);
                         else if (bounded) nl_apply_all<HT, FINE, 1>((int)PSH_NL_TANH, y[g], tanh_tab);
                         else nl_apply_all<HT, FINE>((int)PSH_NL_TANH, y[g], tanh_tab);
                     }
@@ -1772,7 +1795,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         const long tasks16 = (long)npol * ((grp + 15) / 16);
         const int per_wave = (two && tasks16 > 4L * c->num_cus) ? 2 : 1;
         if (two) a.pop_groups = per_wave;
-        a.tanh_tab = c->tanh_tab;
+        a.tanh_tab = c->tanh_tab + (PSH_TANH8_N - 1);
         a.tanh_n = PSH_TANH8_N;
         const size_t lds_w = (4 * ((size_t)sets * a.lds_doubles + OP * 64) + TASK_DOUBLES + TANH8_PAD) * sizeof(double);
         if (lds_w <= c->lds_per_block) {
@@ -1819,7 +1842,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         const long tasks = (long)npol32 * ((grp32 + 15) / 16);
         const int per_wave = tasks > (long)waves * c->num_cus ? 2 : 1;
         a.pop_groups = per_wave;
-        a.tanh_tab = c->tanh_tab;
+        a.tanh_tab = c->tanh_tab + (PSH_TANH8_N - 1);
         a.tanh_n = PSH_TANH8_N;
         const long lanes = (tasks + per_wave - 1) / per_wave * 64;
         // no more waves per workgroup than keep every CU busy
@@ -1870,7 +1893,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         const int BLOCK_POP = 64 * (int)W;
         a.pop_tiles = G;
         a.pop_groups = groups;
-        a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
+        a.tanh_tab = fine ? c->tanh_tab + (PSH_TANH8_N - 1) : c->tanh_tab + PSH_TANH_ODD_N;
         a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
         const size_t lds_pop = waves_bytes + (fine ? fixed_fine : fixed_coarse);
         const long lanes = (tasks + a.pop_groups - 1) / a.pop_groups * 64;
@@ -1896,7 +1919,7 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     }
     const size_t base_doubles = (size_t)total + (BLOCK / 64) * OP * 64 + TASK_DOUBLES;
     const bool fine = (base_doubles + TANH8_PAD) * sizeof(double) <= c->lds_per_block;
-    a.tanh_tab = fine ? c->tanh_tab : c->tanh_tab + PSH_TANH8_N;
+    a.tanh_tab = fine ? c->tanh_tab + (PSH_TANH8_N - 1) : c->tanh_tab + PSH_TANH_ODD_N;
     a.tanh_n = fine ? PSH_TANH8_N : PSH_TANH_TAB_N;
     const size_t lds_bytes = (base_doubles + (fine ? TANH8_PAD : TANH_TAB_PAD)) * sizeof(double);
     if (lds_bytes > c->lds_per_block) { set_err(c, "FNNPolicy too large for the LDS of one workgroup"); return PSH_ERR_UNSUPPORTED; }
@@ -1907,6 +1930,14 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     if (HP <= 32 && !fine) { set_err(c, "no LDS for the tanh table of this FNNPolicy"); return PSH_ERR_UNSUPPORTED; }
     // the usual case has kernels of its own: bare simulation with its default task shape, all-tanh network, fine table
     if (all_tanh && fine && task_has_default_shape<KIND>(d->task)) {
+        // (the bare kernel with the odd tanh table when that table fits next to the staging areas of this block size:
+        // twice the LDS of the fine table for one vector instruction less per activation, ~1 % of a launch)
+        const size_t lds_sgn = ((size_t)total + (BLOCK / 64) * E::O * 64 + TASK_DOUBLES + TANH_ODD_PAD) * sizeof(double);
+        if (!wrapped && HP == 64 && lds_sgn <= c->lds_per_block) {
+            a.tanh_tab = c->tanh_tab;
+            a.tanh_n = PSH_TANH_ODD_N;
+            return launch_persistent(c, k_rollout_fnn<KIND, 64, true, false, false, true, 0, true, true>, BLOCK, lds_sgn, a, E::A, false, st, work_lanes);
+        }
 #define PSH_LAUNCH_FNN_FIXT(HP_)                                                                                                           \
     (wrapped ? launch_persistent(c, k_rollout_fnn<KIND, HP_, true, true, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, has_delay, st, work_lanes) \
              : launch_persistent(c, k_rollout_fnn<KIND, HP_, true, false, false, true, 0, true>, BLOCK, lds_bytes, a, E::A, false, st, work_lanes))

@@ -326,10 +326,10 @@ __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* 
     case 2: y[i] = psh_sigmoid(x[i]); break;
     case 3: psh_sincos(x[i], &s, &c); y[i] = s; break;
     case 4: psh_sincos(x[i], &s, &c); y[i] = c; break;
-    case 6: y[i] = psh_tanh8(x[i], tanh_tab); break;
+    case 6: y[i] = psh_tanh8(x[i], tanh_tab + (PSH_TANH8_N - 1)); break;
     case 7: {
         unsigned hi;
-        const double r = psh_tanh_tab(x[i], tanh_tab + PSH_TANH8_N, &hi);
+        const double r = psh_tanh_tab(x[i], tanh_tab + PSH_TANH_ODD_N, &hi);
         y[i] = hi > PSH_HI_INF ? x[i] : r;
         break;
     }
@@ -372,11 +372,16 @@ extern "C" int psh_create(int hip_device, psh_ctx** out) {
     // the LDS one workgroup may claim through hipFuncAttributeMaxDynamicSharedMemorySize: all of a CU's (160 KB on gfx950)
     c->lds_per_block = prop.maxSharedMemoryPerMultiProcessor > prop.sharedMemPerBlock ? prop.maxSharedMemoryPerMultiProcessor
                                                                                       : prop.sharedMemPerBlock;
-    constexpr size_t tab_n = PSH_TANH8_N + PSH_TANH_TAB_N;
+    constexpr size_t tab_n = PSH_TANH_ODD_N + PSH_TANH_TAB_N;
     std::unique_ptr<double[]> tab(new (std::nothrow) double[tab_n]);
     if (!tab) { delete c; return PSH_ERR_ARG; }
-    for (int j = 0; j < PSH_TANH8_N; ++j) tab[j] = (double)tanhl((long double)j / 256.0L);
-    for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH8_N + j] = (double)tanhl((long double)j / 64.0L);
+    // the fine table of psh_tanh8 is the upper half of the odd one: node 0 is entry PSH_TANH8_N - 1
+    for (int j = 0; j < PSH_TANH8_N; ++j) {
+        const double t = (double)tanhl((long double)j / 256.0L);
+        tab[PSH_TANH8_N - 1 + j] = t;
+        tab[PSH_TANH8_N - 1 - j] = -t;
+    }
+    for (int j = 0; j < PSH_TANH_TAB_N; ++j) tab[PSH_TANH_ODD_N + j] = (double)tanhl((long double)j / 64.0L);
     const size_t tab_bytes = tab_n * sizeof(double);
     bool events_ok = true;
     for (int j = 0; j < PSH_TIMING_RING; ++j)
