@@ -469,9 +469,13 @@ template <int KIND, bool FIXT = false> PSH_DEV double step_rew(const psh_task& t
         // the +-pi fold touches EVERY error component (desired_state.py:125-126), velocities included
 #pragma unroll
         for (int i = 0; i < S; ++i) {
+            // v > pi ? 2 pi - v : v  and then  v < -pi ? -2 pi - v : v, each as one subtraction and a minimum / maximum:
+            // for v <= pi the mirror image 2 pi - v is >= pi >= v, for v > pi it is < pi < v, so min(v, 2 pi - v) IS the
+            // selected value, bit for bit (two instructions instead of a compare and two 32-bit selects); likewise the
+            // maximum with -2 pi - v.  A NaN stays a NaN.
             double v = es[i];
-            v = (v > PSH_PI) ? 2 * PSH_PI - v : v;
-            v = (v < -PSH_PI) ? -2 * PSH_PI - v : v;
+            v = psh_min_raw(v, 2 * PSH_PI - v);
+            v = psh_max_raw(v, -2 * PSH_PI - v);
             es[i] = v;
         }
     }

@@ -35,6 +35,19 @@ PSH_MATH double psh_clip(double x, double lo, double hi) {
     return y;
 }
 
+// Plain v_min_f64 / v_max_f64 (fmin / fmax would first canonicalise each operand, see psh_clip).  One of the two operands
+// comes back unchanged; a NaN only if both are.
+PSH_MATH double psh_min_raw(double a, double b) {
+    double y;
+    asm("v_min_f64 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+PSH_MATH double psh_max_raw(double a, double b) {
+    double y;
+    asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+
 // n / d given r ~ 1/d (relative error far below 2^-26): product plus one residual correction
 PSH_MATH double psh_div_by(double n, double d, double r) {
     const double q = n * r;
