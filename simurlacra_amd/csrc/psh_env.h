@@ -505,9 +505,10 @@ template <int KIND> PSH_DEV bool state_inside(const Env<KIND>& e, bool& nan) {
     e.state_bounds(lo, hi);
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        nan = nan || (e.s[i] != e.s[i]);
-        ok = ok && (e.s[i] >= lo[i]) && (e.s[i] <= hi[i]);
+    for (int i = 0; i < S; ++i) ok = ok && (e.s[i] >= lo[i]) && (e.s[i] <= hi[i]);
+    if (!ok) {  // a NaN fails both comparisons, so only a state outside its bounds needs the test for one
+#pragma unroll
+        for (int i = 0; i < S; ++i) nan = nan || (e.s[i] != e.s[i]);
     }
     return ok;
 }

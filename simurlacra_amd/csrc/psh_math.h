@@ -48,6 +48,15 @@ PSH_MATH double psh_max_raw(double a, double b) {
     return y;
 }
 
+// One Horner step p z + c for a literal c.  Written out because the compiler selects the two-address form for it
+// (v_fmac_f64 with c as the accumulator), which wants c in a vector register pair: two v_mov_b32 per step on the
+// vector ALU.  Here c sits in a scalar register pair (two s_mov_b32 on the scalar unit); the arithmetic is the same fma.
+PSH_MATH double psh_horner(double p, double z, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+    return r;
+}
+
 // n / d given r ~ 1/d (relative error far below 2^-26): product plus one residual correction
 PSH_MATH double psh_div_by(double n, double d, double r) {
     const double q = n * r;
@@ -63,15 +72,15 @@ PSH_MATH double psh_exp_poly(double x, int& k) {
     // q = r + r^2/2! + ... + r^13/13!
     double p = 1.6059043836821613e-10;                     // 1/13!
     p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                  // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                  // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                 // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                   // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                  // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);                  // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                  // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                 // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
+    p = psh_horner(p, r, 2.505210838544172e-08);                  // 1/11!
+    p = psh_horner(p, r, 2.755731922398589e-07);                  // 1/10!
+    p = psh_horner(p, r, 2.7557319223985893e-06);                 // 1/9!
+    p = psh_horner(p, r, 2.48015873015873e-05);                   // 1/8!
+    p = psh_horner(p, r, 1.984126984126984e-04);                  // 1/7!
+    p = psh_horner(p, r, 1.388888888888889e-03);                  // 1/6!
+    p = psh_horner(p, r, 8.333333333333333e-03);                  // 1/5!
+    p = psh_horner(p, r, 4.1666666666666664e-02);                 // 1/4!
+    p = psh_horner(p, r, 1.6666666666666666e-01);                 // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     return p * r;
@@ -235,18 +244,18 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
     // sin kernel on [-pi/4, pi/4]
     double ps = 1.58969099521155010221e-10;
     ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
+    ps = psh_horner(ps, z, 2.75573137070700676789e-06);
+    ps = psh_horner(ps, z, -1.98412698298579493134e-04);
+    ps = psh_horner(ps, z, 8.33333333332248946124e-03);
+    ps = psh_horner(ps, z, -1.66666666666666324348e-01);
     const double sn = fma(ps * z, r, r);
     // cos kernel on [-pi/4, pi/4]
     double pc = -1.13596475577881948265e-11;
     pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
+    pc = psh_horner(pc, z, -2.75573143513906633035e-07);
+    pc = psh_horner(pc, z, 2.48015872894767294178e-05);
+    pc = psh_horner(pc, z, -1.38888888888741095749e-03);
+    pc = psh_horner(pc, z, 4.16666666666666019037e-02);
     const double cs = fma(pc * z, z, fma(-0.5, z, 1.0));
     const double ss = (n & 1) ? cs : sn;
     const double cc = (n & 1) ? sn : cs;

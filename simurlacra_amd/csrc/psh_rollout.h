@@ -358,12 +358,18 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     }
 
     // rollout(): NaN check of the observation, record it, (policy), NaN check of the action
+    // NAN_CHECK = false is for a policy whose action is a NaN whenever an observation is one (a weighted sum of ALL
+    // observations): post_policy's test of the action then ends the rollout at the same step with the same status and
+    // the same rows recorded, and the comparisons per observation are saved.
+    template <bool NAN_CHECK = true>
     PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs) {
         if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
         const int Oe = WRAP ? a.obs_dim : E::O;
         bool nan = false;
+        if constexpr (NAN_CHECK) {
 #pragma unroll
-        for (int r = 0; r < E::O; ++r) nan = nan || (r < Oe && obs[r] != obs[r]);
+            for (int r = 0; r < E::O; ++r) nan = nan || (r < Oe && obs[r] != obs[r]);
+        }
         if (a.obs) {
 #pragma unroll
             for (int r = 0; r < E::O; ++r)
@@ -598,8 +604,8 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
             }
         }
         double obs[E::O], act[E::A];
-        L.pre_policy(a, wrap, obs);
-        if (!L.live) continue;
+        L.template pre_policy<!SIMPLE>(a, wrap, obs);
+        if (!SIMPLE && !L.live) continue;
         if constexpr (SIMPLE) {
 #pragma unroll
             for (int r = 0; r < E::A; ++r) act[r] = wreg[r][0];
