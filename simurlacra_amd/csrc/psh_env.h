@@ -558,13 +558,16 @@ PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr
     curr_step += 1;
     bool nan = false;
     const bool failed = !state_inside<KIND>(e, nan);
-    bool d = failed;
-    if (!inf_steps && curr_step >= max_steps) { d = true; st |= PSH_ST_TIMEOUT; }
-    if (failed) st |= PSH_ST_FAILED;
-    if (nan) st |= PSH_ST_NAN;
-    if (d && ((FIXT ? TaskShape<KIND>::fin : t.final_mode) & PSH_FIN_ENABLED) && !yielded) {
-        yielded = 1;
-        if (failed) rew += final_rew_failed<KIND, FIXT>(e, t, c_max, remaining);
+    const bool timeout = !inf_steps && curr_step >= max_steps;
+    const bool d = failed || timeout;
+    if (d) {  // the status is only touched on the step that ends something: nothing of it on the common path
+        if (timeout) st |= PSH_ST_TIMEOUT;
+        if (failed) st |= PSH_ST_FAILED;
+        if (nan) st |= PSH_ST_NAN;
+        if (((FIXT ? TaskShape<KIND>::fin : t.final_mode) & PSH_FIN_ENABLED) && !yielded) {
+            yielded = 1;
+            if (failed) rew += final_rew_failed<KIND, FIXT>(e, t, c_max, remaining);
+        }
     }
     done = d;
     return rew;

@@ -63,10 +63,18 @@ PSH_MATH double psh_div_by(double n, double d, double r) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// The nearest integer to x c for |x c| < 2^31, as a double and as an int: the magic-number addition 1.5 * 2^52 leaves it
+// in the low word of the sum in two's complement (an fma and a subtraction, one rounding, instead of a product, v_rndne
+// and a quarter-rate conversion).
+PSH_MATH double psh_round_scaled(double x, double c, int& n) {
+    const double t = fma(x, c, 6755399441055744.0);
+    n = __double2loint(t);
+    return t - 6755399441055744.0;
+}
+
 // exp(x) - 1 split as (k, q): exp(x) = 2^k * (1 + q), |q| <= 0.42.  Shared by exp, tanh and sigmoid.
 PSH_MATH double psh_exp_poly(double x, int& k) {
-    const double kd = rint(x * 1.4426950408889634074);
-    k = (int)kd;
+    const double kd = psh_round_scaled(x, 1.4426950408889634074, k);
     double r = fma(-kd, 6.93147180369123816490e-01, x);   // ln2 high part (33 bits): the product is exact
     r = fma(-kd, 1.90821492927058770002e-10, r);          // ln2 low part
     // q = r + r^2/2! + ... + r^13/13!
@@ -87,8 +95,10 @@ PSH_MATH double psh_exp_poly(double x, int& k) {
 }
 
 PSH_MATH double psh_exp(double x) {
-    x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
-    x = (x > 710.0) ? 710.0 : x;     // above this exp overflows to +inf
+    if (!(fabs(x) <= 700.0)) {           // rare: one comparison on the common path instead of two and four selects
+        x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
+        x = (x > 710.0) ? 710.0 : x;     // above this exp overflows to +inf
+    }
     int k;
     const double q = psh_exp_poly(x, k);
     return ldexp(1.0 + q, k);
@@ -235,8 +245,8 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
         sincos(x, s, c);
         return;
     }
-    const double nd = rint(x * 6.36619772367581382433e-01);  // 2/pi
-    const int n = (int)nd;
+    int n;
+    const double nd = psh_round_scaled(x, 6.36619772367581382433e-01, n);  // 2/pi
     double r = fma(-nd, 1.57079632673412561417e+00, x);      // pi/2, first 33 bits
     r = fma(-nd, 6.07710050630396597660e-11, r);             // next 33 bits
     r = fma(-nd, 2.02226624879595063154e-21, r);             // tail
@@ -259,8 +269,9 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
     const double cs = fma(pc * z, z, fma(-0.5, z, 1.0));
     const double ss = (n & 1) ? cs : sn;
     const double cc = (n & 1) ? sn : cs;
-    *s = (n & 2) ? -ss : ss;
-    *c = ((n + 1) & 2) ? -cc : cc;
+    // quadrants 2, 3 negate the sine and quadrants 1, 2 the cosine: bit 1 of n (of n + 1) moved onto the sign bit
+    *s = __hiloint2double(__double2hiint(ss) ^ (int)(((unsigned)n << 30) & 0x80000000u), __double2loint(ss));
+    *c = __hiloint2double(__double2hiint(cc) ^ (int)(((unsigned)(n + 1) << 30) & 0x80000000u), __double2loint(cc));
 }
 
 // C fmod (sign of x, exact) for quotients below 2^52; library path otherwise

@@ -147,7 +147,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     E e;
     double c_max, ret;
     long i;           // env this lane currently runs, -1: none
-    int curr_step, yielded, st, k;
+    int yielded, st, k;   // k: steps taken = SimPyEnv._curr_step (the two always agree here)
     int delay, qpos;  // WRAP: ActDelayWrapper delay of this env, write position of its ring buffer
     double delay_pre[E::A];  // WRAP: the ring-buffer entry the next step will take out, requested a step ahead
     bool done, live;  // live: this lane still has steps to execute
@@ -293,7 +293,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         } else {
             e.reset(init, a.init_dim, false);
         }
-        ret = 0.; curr_step = 0; yielded = 0; k = 0; done = false; pad_row = -1;
+        ret = 0.; yielded = 0; k = 0; done = false; pad_row = -1;
         st = bad_index ? PSH_ST_BAD_INDEX : 0;  // not run: stored with length 0 at the next turnover
         live = a.max_steps > 0 && !bad_index;
         if constexpr (WRAP) {
@@ -404,6 +404,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         if (nan) { st |= PSH_ST_NAN; live = false; return; }
         const bool simplified = (a.flags & PSH_F_SIMPLIFIED_DYN) != 0;
         double rew;
+        int cs = k;   // the environment's step counter: k + 1 after env_step
         if constexpr (WRAP) {
             // EnvWrapperAct.step (environment_wrappers/base.py:168-174), outermost wrapper first
             double inner[E::A];
@@ -445,7 +446,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
                     for (int r = 0; r < E::A; ++r) inner[r] = inner[r] + (n[r] * wrap.act_noise_std[r] + wrap.act_noise_mean[r]);
                 }
             }
-            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
+            rew = env_step<KIND, FIXT>(e, task, c_max, cs, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
@@ -469,7 +470,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
             }
-            rew = env_step<KIND, FIXT>(e, task, c_max, curr_step, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
+            rew = env_step<KIND, FIXT>(e, task, c_max, cs, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
             if (a.act) {
 #pragma unroll
                 for (int r = 0; r < E::A; ++r)
@@ -478,9 +479,9 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         }
         if (a.rew) traj_store(a.rew + traj_off(k, 0, i, a.rew_sk, 0u, a.rew_si), rew);
         ret += rew;
-        k += 1;
-        if (st & PSH_ST_NAN) live = false;
-        if ((done && (a.flags & PSH_F_STOP_ON_DONE)) || curr_step >= a.max_steps) live = false;
+        k = cs;
+        // a NaN state has failed its bounds and the last step has timed out: both arrive with `done` set
+        if (done && ((a.flags & PSH_F_STOP_ON_DONE) || (st & (PSH_ST_NAN | PSH_ST_TIMEOUT)))) live = false;
         if constexpr (WRAP) {
             if (live && a.bernoulli > 0.) {  // stochastic reset (sampling/rollout.py:248-254)
                 double u0, u1;
