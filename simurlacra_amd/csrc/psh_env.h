@@ -542,7 +542,7 @@ PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr
     // BoxSpace.project (spaces/box.py:144-148): an action inside its bounds is passed on as it is (the caller's array, which
     // only QBallBalancerSim writes to), any other one is clipped; clipping leaves an inside action unchanged
 #pragma unroll
-    for (int i = 0; i < A; ++i) a[i] = psh_clip(act_io[i], alo[i], ahi[i]);
+    for (int i = 0; i < A; ++i) a[i] = psh_clip_sym(act_io[i], ahi[i]);   // every simulation's action space is symmetric (act_bounds)
     if constexpr (KIND == PSH_ENV_QBB) {
         bool inside = true;
 #pragma unroll

@@ -35,6 +35,14 @@ PSH_MATH double psh_clip(double x, double lo, double hi) {
     return y;
 }
 
+// psh_clip(x, -hi, hi): the negation is an operand modifier, not an instruction
+PSH_MATH double psh_clip_sym(double x, double hi) {
+    double y;
+    asm("v_max_f64 %0, %1, -%2" : "=v"(y) : "v"(x), "v"(hi));
+    asm("v_min_f64 %0, %1, %2" : "=v"(y) : "v"(y), "v"(hi));
+    return y;
+}
+
 // Plain v_min_f64 / v_max_f64 (fmin / fmax would first canonicalise each operand, see psh_clip).  One of the two operands
 // comes back unchanged; a NaN only if both are.
 PSH_MATH double psh_min_raw(double a, double b) {
@@ -96,6 +104,7 @@ PSH_MATH double psh_exp_poly(double x, int& k) {
 
 PSH_MATH double psh_exp(double x) {
     if (!(fabs(x) <= 700.0)) {           // rare: one comparison on the common path instead of two and four selects
+        asm volatile("");                // (keeps it a branch: as selects the three comparisons would all run)
         x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
         x = (x > 710.0) ? 710.0 : x;     // above this exp overflows to +inf
     }

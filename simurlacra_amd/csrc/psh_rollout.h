@@ -465,6 +465,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
 #pragma unroll
             for (int r = 0; r < E::A; ++r) inner[r] = act[r];
             if (act_norm) {
+                asm volatile("");   // a wave-uniform branch, not four instructions and two selects on every step
                 double lo[E::A], hi[E::A];
                 e.act_bounds(lo, hi);
 #pragma unroll
