@@ -99,9 +99,11 @@ static inline int scratch_doubles(psh_ctx* c, int which, size_t need, double** o
 
 // Persistent launch: as many workgroups as the device keeps resident (lanes pull envs from the queue), fewer when the
 // batch is smaller than that.
-template <class K> static unsigned persistent_grid(psh_ctx* c, K kernel, int block, size_t lds_bytes, long n_envs) {
+// max_per_cu > 0 limits the workgroups per CU below what fits.
+template <class K> static unsigned persistent_grid(psh_ctx* c, K kernel, int block, size_t lds_bytes, long n_envs, int max_per_cu = 0) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
     const long resident = (long)per_cu * c->num_cus;
     const long need = (n_envs + block - 1) / block;
     return (unsigned)(need < resident ? need : resident);

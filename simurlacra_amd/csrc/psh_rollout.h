@@ -1595,10 +1595,10 @@ static inline int check_wrap(psh_ctx* c, const psh_wrappers& w, int O, int* obs_
 // Persistent launch of a rollout kernel: grid from the occupancy query, the ActDelay ring buffers sized to it.
 template <class K>
 static inline int launch_persistent(psh_ctx* c, K kernel, int block, size_t lds_bytes, RolloutArgs& a, int act_dim, bool need_delay_q,
-                                    hipStream_t st, long work_lanes = -1) {
+                                    hipStream_t st, long work_lanes = -1, int max_per_cu = 0) {
     if (lds_bytes)
         PSH_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, work_lanes < 0 ? (long)a.n_envs : work_lanes);
+    const unsigned grid = persistent_grid(c, kernel, block, lds_bytes, work_lanes < 0 ? (long)a.n_envs : work_lanes, max_per_cu);
     a.n_lanes = (long)grid * block;
     if (need_delay_q) {
         const int rc = scratch_doubles(c, PSH_SCR_DELAY, (size_t)PSH_MAX_DELAY * act_dim * a.n_lanes, &a.delay_q);
@@ -1696,15 +1696,22 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
                             (p.n_feats == 2 && p.feats[0] == PSH_FEAT_CONST && p.feats[1] == PSH_FEAT_IDENTITY);
         // the usual case gets a kernel of its own: bare simulation, const / identity features, the simulation's default task
         const bool fixt = simple && task_has_default_shape<KIND>(d->task);
+        // At most four waves per SIMD for the simulations with a step of a few hundred instructions: they are bound by vector
+        // instruction issue from four waves on, and a fifth or sixth (the bare kernels of BallOnBeam and QQubeStab have the
+        // registers for them) only slows every wave's step down -- which is what a launch of short episodes waits for at its
+        // end, when the few environments that run to the horizon are left (2^20 rollouts, BallOnBeam 75 -> 80 G, QQubeStab 47.5
+        // -> 50.7 G env-steps/s).  The two-state simulations have steps short enough to be latency-bound and gain from every
+        // wave (OneMassOscillator 663 -> 727 G, Pendulum 216 -> 243 G with six instead of four).
+        const int lin_per_cu = E::S <= 2 ? 0 : 4;
 #define PSH_LAUNCH_LIN(PER_ENV_, WRAP_)                                                                                     \
-    (simple ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st) \
-            : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st))
+    (simple ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu) \
+            : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu))
         if (fixt && wrapped)
-            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, true, true, true>, 256, 0, a, E::A, has_delay, st)
-                           : launch_persistent(c, k_rollout_linear<KIND, false, true, true, true>, 256, 0, a, E::A, has_delay, st);
+            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, true, true, true>, 256, 0, a, E::A, has_delay, st, -1, lin_per_cu)
+                           : launch_persistent(c, k_rollout_linear<KIND, false, true, true, true>, 256, 0, a, E::A, has_delay, st, -1, lin_per_cu);
         if (fixt)
-            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, false, true, true>, 256, 0, a, E::A, false, st)
-                           : launch_persistent(c, k_rollout_linear<KIND, false, false, true, true>, 256, 0, a, E::A, false, st);
+            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, false, true, true>, 256, 0, a, E::A, false, st, -1, lin_per_cu)
+                           : launch_persistent(c, k_rollout_linear<KIND, false, false, true, true>, 256, 0, a, E::A, false, st, -1, lin_per_cu);
         if (per_env) return wrapped ? PSH_LAUNCH_LIN(true, true) : PSH_LAUNCH_LIN(true, false);
         return wrapped ? PSH_LAUNCH_LIN(false, true) : PSH_LAUNCH_LIN(false, false);
 #undef PSH_LAUNCH_LIN
