@@ -456,7 +456,8 @@ template <int KIND, bool FIXT = false> PSH_DEV double task_c_max(const Env<KIND>
     return -1.0 * log(t.min_rew) / (FIXT ? quadr_cost_diag<S, A>(t, om, am) : quadr_cost<S, A>(t, om, am));
 }
 
-template <int KIND, bool FIXT = false> PSH_DEV double step_rew(const psh_task& t, double c_max, const double* state, const double* act) {
+template <int KIND, bool FIXT = false>
+PSH_DEV double step_rew(const psh_task& t, double c_max, const double* state, const double* act) {
     constexpr int S = Env<KIND>::S, A = Env<KIND>::A;
     using Sh = TaskShape<KIND>;
     double es[S], ea[A];
@@ -492,10 +493,25 @@ template <int KIND, bool FIXT = false> PSH_DEV double step_rew(const psh_task& t
         const double cost_pole = t.swingup[3] * (eth * eth) + log(eth * eth + t.swingup[4]);
         return -t.swingup[0] * cost_pole - t.swingup[1] * fabs(ex) - t.swingup[2] * (ea[0] * ea[0]) + 10;
     }
-    const double cost = FIXT ? quadr_cost_diag<S, A>(t, es, ea) : quadr_cost<S, A>(t, es, ea);
+    // FIXT takes Q and R as diagonal.  The reference multiplies the full matrices (rewards.py:67-72: err.dot(Q).dot(err)), and
+    // an infinite error component times one of their zeros is a NaN there, where the diagonal form says infinity: a cost
+    // that is not finite is computed again the reference's way.  An infinite component needs a state that has left its
+    // bounds (or an initial state that was never inside them): rare.  For the exponential rewards the test is the one exp
+    // needs anyway; the plain quadratic one is corrected by env_step on the step that fails the bounds, which a step that
+    // starts from an infinite state always does.
+    constexpr bool DIAG = FIXT;
+    double cost = DIAG ? quadr_cost_diag<S, A>(t, es, ea) : quadr_cost<S, A>(t, es, ea);
     if (kind == PSH_REW_QUADR) return -cost;
-    if (kind == PSH_REW_EXP_QUADR) return psh_exp(-cost);
-    return psh_exp(-c_max * cost);
+    double x = kind == PSH_REW_EXP_QUADR ? -cost : -c_max * cost;
+    if (!(fabs(x) <= PSH_EXP_FAST)) {
+        asm volatile("");
+        if (DIAG) {
+            cost = quadr_cost<S, A>(t, es, ea);
+            x = kind == PSH_REW_EXP_QUADR ? -cost : -c_max * cost;
+        }
+        x = psh_exp_clamp(x);
+    }
+    return psh_exp_core(x);
 }
 
 // BoxSpace.contains on the state: inclusive bounds; a NaN makes the reference raise, here it sets `nan`
@@ -561,6 +577,30 @@ PSH_DEV double env_step(Env<KIND>& e, const psh_task& t, double c_max, int& curr
     const bool timeout = !inf_steps && curr_step >= max_steps;
     const bool d = failed || timeout;
     if (d) {  // the status is only touched on the step that ends something: nothing of it on the common path
+        // Two places where the reference multiplies by a zero that the kernels leave out, which matters for an infinite state
+        // only (0 * inf is a NaN).  A step that starts from an infinite component ends with a non-finite state, which fails
+        // the bounds, so both are dealt with here and cost the other steps nothing; they work from the new state, because
+        // keeping the old one alive up to here would cost every step of the small simulations two register copies.
+        if constexpr (KIND == PSH_ENV_OMO) {
+            // one_mass_oscillator.py:80-85, A.dot(state) + B.dot(act) with A = [[0, 1], [-omega^2, -2 zeta omega]]: an infinite
+            // position makes the new position a NaN (0 * inf in A's first row), where x + v dt keeps it infinite.  The new
+            // velocity tells that case from an infinite old velocity: -omega^2 * (+-inf) is an infinity, while an infinite
+            // velocity cancels against its own damping term into a NaN (then the status holds PSH_ST_NAN either way).
+            const double inf = __builtin_inf();
+            if (failed && fabs(e.s[0]) == inf && fabs(e.s[1]) == inf) { e.s[0] = __builtin_nan(""); nan = true; }
+        }
+        if constexpr (FIXT && TaskShape<KIND>::rew == PSH_REW_QUADR) {
+            // step_rew, the plain quadratic reward from the diagonals: -inf where the reference's full matrices give a NaN for
+            // an infinite error component.  Told apart from a cost that merely overflowed (an error beyond 1e154, or an
+            // infinite action: -inf in the reference too) by the new state, which is non-finite after an infinite one.
+            // (Not covered: a finite state beyond 1e154 that the step itself takes to infinity.)
+            if (failed && rew == -__builtin_inf()) {
+                bool finite = true;
+#pragma unroll
+                for (int i = 0; i < Env<KIND>::S; ++i) finite = finite && fabs(e.s[i]) <= 1.79e308;
+                if (!finite) rew = __builtin_nan("");
+            }
+        }
         if (timeout) st |= PSH_ST_TIMEOUT;
         if (failed) st |= PSH_ST_FAILED;
         if (nan) st |= PSH_ST_NAN;

@@ -102,15 +102,23 @@ PSH_MATH double psh_exp_poly(double x, int& k) {
     return p * r;
 }
 
-PSH_MATH double psh_exp(double x) {
-    if (!(fabs(x) <= 700.0)) {           // rare: one comparison on the common path instead of two and four selects
-        asm volatile("");                // (keeps it a branch: as selects the three comparisons would all run)
-        x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
-        x = (x > 710.0) ? 710.0 : x;     // above this exp overflows to +inf
-    }
+// exp for |x| <= 746 (psh_exp_clamp brings any other argument there)
+PSH_MATH double psh_exp_core(double x) {
     int k;
     const double q = psh_exp_poly(x, k);
     return ldexp(1.0 + q, k);
+}
+#define PSH_EXP_FAST 700.0   // arguments up to here need no clamp
+PSH_MATH double psh_exp_clamp(double x) {
+    x = (x < -746.0) ? -746.0 : x;   // NaN stays NaN (comparisons are false); below this exp underflows to 0
+    return (x > 710.0) ? 710.0 : x;  // above this exp overflows to +inf
+}
+PSH_MATH double psh_exp(double x) {
+    if (!(fabs(x) <= PSH_EXP_FAST)) {    // rare: one comparison on the common path instead of two and four selects
+        asm volatile("");                // (keeps it a branch: as selects the three comparisons would all run)
+        x = psh_exp_clamp(x);
+    }
+    return psh_exp_core(x);
 }
 
 PSH_MATH double psh_tanh(double x) {
