@@ -173,7 +173,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     // COHORT (a.cohort = 16, launches that record time-major trajectories): the lanes of an aligned group of 16 take 16
     // consecutive environments together and give them back together, when the last of them has ended.  The group then
     // stays in lock step, so every trajectory store of it is one whole 128-byte line of a row (a lane whose environment has
-    // ended pads its rows with NaN until the group is done, see pad_rows): environments that end early otherwise leave
+    // ended pads its rows with NaN until the group is done, see pre_policy): environments that end early otherwise leave
     // their neighbours writing 8- to 120-byte parts of a line, which the memory system turns into read-modify-write
     // cycles.  Lanes idle for max - own length of their group; what that costs is less than what the partial lines did.
     template <int BATCH = 1> PSH_DEV void turnover(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap) {
@@ -361,8 +361,12 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
     // NAN_CHECK = false is for a policy whose action is a NaN whenever an observation is one (a weighted sum of ALL
     // observations): post_policy's test of the action then ends the rollout at the same step with the same status and
     // the same rows recorded, and the comparisons per observation are saved.
+    // pad (cohort mode): this lane's environment has ended while others of its group still run.  It goes through the same
+    // stores as they do and writes its share of the rows they write -- its final observation first (row k, pad_row == k),
+    // NaN afterwards -- so that the group's stores stay whole lines and the wave runs ONE instruction stream per step
+    // (as a pass of its own for the ended lanes the padding cost BallOnBeam's recording launch a sixth of its time).
     template <bool NAN_CHECK = true>
-    PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs) {
+    PSH_DEV void pre_policy(const RolloutArgs& a, const psh_wrappers& wrap, double* obs, bool pad = false) {
         if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
         const int Oe = WRAP ? a.obs_dim : E::O;
         bool nan = false;
@@ -371,14 +375,62 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
             for (int r = 0; r < E::O; ++r) nan = nan || (r < Oe && obs[r] != obs[r]);
         }
         if (a.obs) {
+            const int row = pad ? pad_row : k;
+            const bool blank = pad && pad_row != k;
+            if (!pad || row <= a.max_steps) {   // (a stepping lane's row is k < max_steps)
 #pragma unroll
-            for (int r = 0; r < E::O; ++r)
-                if (r < Oe) traj_store(a.obs + traj_off(k, r, i, a.obs_sk, a.obs_sr, a.obs_si), obs[r]);
+                for (int r = 0; r < E::O; ++r)
+                    if (r < Oe) traj_store(a.obs + traj_off(row, r, i, a.obs_sk, a.obs_sr, a.obs_si), blank ? __builtin_nan("") : obs[r]);
+            }
         }
-        if (nan) { st |= PSH_ST_NAN; live = false; }
+        if (nan && !pad) { st |= PSH_ST_NAN; live = false; }
     }
 
-    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act) {
+    // PADK: the caller's lanes may be padding (see pre_policy); the rows of the action and the reward are then written
+    // here, by stepping and padding lanes alike.  Without it step_env records them itself, as it goes.
+    template <bool PADK = false>
+    PSH_DEV void post_policy(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act, bool pad = false) {
+        double rew;
+        int cs = k;   // the environment's step counter: k + 1 after env_step
+        bool stepped = false;
+        if constexpr (PADK) {
+            double act_rec[E::A];   // what this step's row of the action receives
+            rew = __builtin_nan("");
+#pragma unroll
+            for (int r = 0; r < E::A; ++r) act_rec[r] = __builtin_nan("");
+            if (!pad) step_env<false>(a, task, wrap, act, act_rec, rew, cs, stepped);
+            const int row = pad ? pad_row : k;
+            if (pad ? row < a.max_steps : stepped) {
+                if (a.act) {
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(row, r, i, a.act_sk, a.act_sr, a.act_si), act_rec[r]);
+                }
+                if (a.rew) traj_store(a.rew + traj_off(row, 0, i, a.rew_sk, 0u, a.rew_si), rew);
+            }
+            if (pad) { pad_row += 1; return; }
+        } else {
+            step_env<true>(a, task, wrap, act, nullptr, rew, cs, stepped);
+        }
+        if (!stepped) return;
+        ret += rew;
+        k = cs;
+        // a NaN state has failed its bounds and the last step has timed out: both arrive with `done` set
+        if (done && ((a.flags & PSH_F_STOP_ON_DONE) || (st & (PSH_ST_NAN | PSH_ST_TIMEOUT)))) live = false;
+        if constexpr (WRAP) {
+            if (live && a.bernoulli > 0.) {  // stochastic reset (sampling/rollout.py:248-254)
+                double u0, u1;
+                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)(k - 1), PSH_STREAM_BERNOULLI, u0, u1);
+                if (u0 < a.bernoulli) { st |= PSH_ST_BERNOULLI; live = false; }
+            }
+        }
+    }
+
+    // The part of a step between the policy's output and the recording of its rows: exploration noise, NaN test of the
+    // action, action wrappers, SimPyEnv.step.  stepped stays false if the action was a NaN (nothing recorded for the step).
+    // STORE: the rows of the action and the reward are written here; otherwise the action's comes back in act_rec.
+    template <bool STORE>
+    PSH_DEV void step_env(const RolloutArgs& a, const psh_task& task, const psh_wrappers& wrap, double* act, double* act_rec,
+                          double& rew, int& cs, bool& stepped) {
         if constexpr (WRAP) {
             // StochasticActionExplStrat.forward (exploration/stochastic_action.py:42-68): the exploratory action
             // replaces the policy's output for everything that follows
@@ -403,8 +455,7 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
         for (int r = 0; r < E::A; ++r) nan = nan || (act[r] != act[r]);
         if (nan) { st |= PSH_ST_NAN; live = false; return; }
         const bool simplified = (a.flags & PSH_F_SIMPLIFIED_DYN) != 0;
-        double rew;
-        int cs = k;   // the environment's step counter: k + 1 after env_step
+        stepped = true;
         if constexpr (WRAP) {
             // EnvWrapperAct.step (environment_wrappers/base.py:168-174), outermost wrapper first
             double inner[E::A];
@@ -447,12 +498,22 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
                 }
             }
             rew = env_step<KIND, FIXT>(e, task, c_max, cs, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
-            if (a.act) {
+            if constexpr (!STORE) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
+                for (int r = 0; r < E::A; ++r) act_rec[r] = act[r];
+            }
+            if (a.act) {
+                if constexpr (STORE) {
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act[r]);
+                }
                 // ActDelayWrapper queues the caller's array objects: without an array-creating wrapper the simulation
                 // wrote its dead zone (QBB) into the action recorded `delay` steps ago
-                if (rec_alias && k - delay >= 0) {
+                // (with no delay that is this step's own row: after the store above, or into what the caller stores)
+                if (!STORE && rec_alias && delay == 0) {
+#pragma unroll
+                    for (int r = 0; r < E::A; ++r) act_rec[r] = inner[r];
+                } else if (rec_alias && k - delay >= 0) {
 #pragma unroll
                     for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(k - delay, r, i, a.act_sk, a.act_sr, a.act_si), inner[r]);
                 }
@@ -472,53 +533,20 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
                 for (int r = 0; r < E::A; ++r) inner[r] = lo[r] + (inner[r] + 1) * (hi[r] - lo[r]) / 2;
             }
             rew = env_step<KIND, FIXT>(e, task, c_max, cs, yielded, inner, a.dt, a.max_steps, false, simplified, done, st);
-            if (a.act) {
+            if constexpr (STORE) {
+                if (a.act) {
 #pragma unroll
-                for (int r = 0; r < E::A; ++r)
-                    traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act_norm ? act[r] : inner[r]);
+                    for (int r = 0; r < E::A; ++r)
+                        traj_store(a.act + traj_off(k, r, i, a.act_sk, a.act_sr, a.act_si), act_norm ? act[r] : inner[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E::A; ++r) act_rec[r] = act_norm ? act[r] : inner[r];
             }
         }
-        if (a.rew) traj_store(a.rew + traj_off(k, 0, i, a.rew_sk, 0u, a.rew_si), rew);
-        ret += rew;
-        k = cs;
-        // a NaN state has failed its bounds and the last step has timed out: both arrive with `done` set
-        if (done && ((a.flags & PSH_F_STOP_ON_DONE) || (st & (PSH_ST_NAN | PSH_ST_TIMEOUT)))) live = false;
-        if constexpr (WRAP) {
-            if (live && a.bernoulli > 0.) {  // stochastic reset (sampling/rollout.py:248-254)
-                double u0, u1;
-                psh_draw2(wrap.noise_seed, wrap.env_offset + (uint64_t)i, (uint32_t)(k - 1), PSH_STREAM_BERNOULLI, u0, u1);
-                if (u0 < a.bernoulli) { st |= PSH_ST_BERNOULLI; live = false; }
-            }
+        if constexpr (STORE) {
+            if (a.rew) traj_store(a.rew + traj_off(k, 0, i, a.rew_sk, 0u, a.rew_si), rew);
         }
-    }
-
-    // Cohort mode, a lane whose environment has ended while others of its octet still run: one call per step of the
-    // neighbours writes this environment's share of the rows they write -- its final observation first, NaN afterwards.
-    PSH_DEV void pad_rows(const RolloutArgs& a, const psh_wrappers& wrap) {
-        const double nan = __builtin_nan("");
-        const int Oe = WRAP ? a.obs_dim : E::O;
-        if (pad_row < 0) {
-            pad_row = k;
-            if (a.obs) {
-                double obs[E::O];
-                if (WRAP && a.wrap_obs_ops) wrapped_obs(a, wrap, (uint32_t)k, obs); else e.observe(obs);
-#pragma unroll
-                for (int r = 0; r < E::O; ++r)
-                    if (r < Oe) traj_store(a.obs + traj_off(k, r, i, a.obs_sk, a.obs_sr, a.obs_si), obs[r]);
-            }
-        } else if (a.obs) {
-#pragma unroll
-            for (int r = 0; r < E::O; ++r)
-                if (r < Oe) traj_store(a.obs + traj_off(pad_row, r, i, a.obs_sk, a.obs_sr, a.obs_si), nan);
-        }
-        if (pad_row < a.max_steps) {
-            if (a.act) {
-#pragma unroll
-                for (int r = 0; r < E::A; ++r) traj_store(a.act + traj_off(pad_row, r, i, a.act_sk, a.act_sr, a.act_si), nan);
-            }
-            if (a.rew) traj_store(a.rew + traj_off(pad_row, 0, i, a.rew_sk, 0u, a.rew_si), nan);
-        }
-        pad_row += 1;
     }
 
     PSH_DEV void store(const RolloutArgs& a, const psh_wrappers& wrap, int extra_status = 0, bool final_obs_written = false) {
@@ -548,7 +576,9 @@ template <int KIND, bool WRAP, bool FIXT = false, bool ANORM = false> struct Lan
 // dispatch costs scalar instructions on every step (the scalar unit of a CU, shared by its four SIMDs, is what bounds
 // the cheap simulations).
 // FIXT: the task has the default shape of this simulation (TaskShape), decided at compile time.
-template <int KIND, bool PER_ENV, bool WRAP, bool SIMPLE = false, bool FIXT = false>
+// PAD: a launch that records time-major trajectories, whose lanes run in cohorts (Lane::turnover) and pad the rows of
+// environments that have ended (Lane::pre_policy); a kernel of its own, so that the others carry none of it.
+template <int KIND, bool PER_ENV, bool WRAP, bool SIMPLE = false, bool FIXT = false, bool PAD = false>
 // (waves per SIMD the register allocation aims at: the wrapped kernels land a few registers above the 168 that three
 // waves per SIMD allow unless told to stay below, at the price of a few spills -- QQube behind ActNormWrapper, 2^20
 // rollouts: 8.5 -> 7.5 ms; the per-environment-policy variants mostly run populations of a wave or two per SIMD, which
@@ -593,10 +623,8 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
         if (!__all(L.live)) {
             L.template turnover<8>(a, task, wrap);
             if (!__any(L.i >= 0)) break;  // every lane of the wave is out of work
-            if (!L.live) {                // (a lane without an env is not live)
-                if (a.cohort && L.i >= 0) L.pad_rows(a, wrap);
-                continue;
-            }
+            // (a lane without an env is not live; one whose env has ended while its cohort still runs pads its rows)
+            if (!L.live && !(PAD && L.i >= 0)) continue;
             if (PER_ENV && w_env != L.i) {
                 const long row = a.pol.policy_index ? (long)a.pol.policy_index[L.i]
                                                     : (a.pol.policy_group > 0 ? L.i / a.pol.policy_group : 0);
@@ -606,8 +634,10 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
             }
         }
         double obs[E::O], act[E::A];
-        L.template pre_policy<!SIMPLE>(a, wrap, obs);
-        if (!SIMPLE && !L.live) continue;
+        const bool pad = PAD && !L.live;
+        if (pad && L.pad_row < 0) L.pad_row = L.k;
+        L.template pre_policy<!SIMPLE>(a, wrap, obs, pad);
+        if (!SIMPLE && !L.live && !pad) continue;
         if constexpr (SIMPLE) {
 #pragma unroll
             for (int r = 0; r < E::A; ++r) act[r] = wreg[r][0];
@@ -617,7 +647,7 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
 #pragma unroll
                 for (int r = 0; r < E::A; ++r) act[r] += wreg[r][1 + q] * obs[q];
             }
-            L.post_policy(a, task, wrap, act);
+            L.template post_policy<PAD>(a, task, wrap, act, pad);
             continue;
         }
 #pragma unroll
@@ -707,7 +737,7 @@ __global__ __launch_bounds__(256, KIND == PSH_ENV_QBB ? 1 : (WRAP && !PER_ENV ? 
                 n += Oe;
             }
         }
-        L.post_policy(a, task, wrap, act);
+        L.template post_policy<PAD>(a, task, wrap, act, pad);
     }
 }
 
@@ -1703,17 +1733,15 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
         // -> 50.7 G env-steps/s).  The two-state simulations have steps short enough to be latency-bound and gain from every
         // wave (OneMassOscillator 663 -> 727 G, Pendulum 216 -> 243 G with six instead of four).
         const int lin_per_cu = E::S <= 2 ? 0 : 4;
-#define PSH_LAUNCH_LIN(PER_ENV_, WRAP_)                                                                                     \
-    (simple ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu) \
-            : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu))
-        if (fixt && wrapped)
-            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, true, true, true>, 256, 0, a, E::A, has_delay, st, -1, lin_per_cu)
-                           : launch_persistent(c, k_rollout_linear<KIND, false, true, true, true>, 256, 0, a, E::A, has_delay, st, -1, lin_per_cu);
-        if (fixt)
-            return per_env ? launch_persistent(c, k_rollout_linear<KIND, true, false, true, true>, 256, 0, a, E::A, false, st, -1, lin_per_cu)
-                           : launch_persistent(c, k_rollout_linear<KIND, false, false, true, true>, 256, 0, a, E::A, false, st, -1, lin_per_cu);
+#define PSH_LIN_KERNEL(PER_ENV_, WRAP_, SIMPLE_, FIXT_) \
+    (a.cohort ? launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, SIMPLE_, FIXT_, true>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu) \
+              : launch_persistent(c, k_rollout_linear<KIND, PER_ENV_, WRAP_, SIMPLE_, FIXT_, false>, 256, 0, a, E::A, WRAP_ && has_delay, st, -1, lin_per_cu))
+#define PSH_LAUNCH_LIN(PER_ENV_, WRAP_) (simple ? PSH_LIN_KERNEL(PER_ENV_, WRAP_, true, false) : PSH_LIN_KERNEL(PER_ENV_, WRAP_, false, false))
+        if (fixt && wrapped) return per_env ? PSH_LIN_KERNEL(true, true, true, true) : PSH_LIN_KERNEL(false, true, true, true);
+        if (fixt) return per_env ? PSH_LIN_KERNEL(true, false, true, true) : PSH_LIN_KERNEL(false, false, true, true);
         if (per_env) return wrapped ? PSH_LAUNCH_LIN(true, true) : PSH_LAUNCH_LIN(true, false);
         return wrapped ? PSH_LAUNCH_LIN(false, true) : PSH_LAUNCH_LIN(false, false);
+#undef PSH_LIN_KERNEL
 #undef PSH_LAUNCH_LIN
     }
     if (p.kind != PSH_POL_FNN) { set_err(c, "unknown policy kind"); return PSH_ERR_ARG; }
