@@ -916,7 +916,7 @@ def test_a_wrapper_list_without_noise_does_not_pay_for_the_noise_draws(eng, kind
     assert t_norm < 1.9*t_bare, (t_bare, t_norm)
 
 
-@pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 1200.)], ids=['omo', 'bob'])
+@pytest.mark.parametrize('kind,min_gbs', [(abi.ENV_OMO, 3000.), (abi.ENV_BOB, 1600.)], ids=['omo', 'bob'])
 def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, min_gbs):
     """ 2^21 environments with full trajectories (T = 500): OneMassOscillator runs every episode to the end (34 GB of
     trajectory), BallOnBeam ends after 69 steps on average, so every lane is refilled seven times and the wave's lanes
