@@ -14,14 +14,20 @@ from .base import EnvWrapper
 from .utils import all_envs, inner_env, remove_env
 
 
+def _require(obj, cls, allow_none: bool = False):
+    """ The reference's type checks in one place: anything but an instance of cls (or None where allowed) is a TypeErr. """
+    if not (isinstance(obj, cls) or (allow_none and obj is None)):
+        raise TypeErr(given=obj, expected_type=cls)
+    return obj
+
+
 class DomainRandWrapper(EnvWrapper):
+    """ Base of the randomizing wrappers (:13-48): holds the randomizer, wraps a simulation only. """
+
     def __init__(self, wrapped_env, randomizer):
-        if not isinstance(inner_env(wrapped_env), SimEnv):
-            raise TypeErr(given=wrapped_env, expected_type=SimEnv)
-        if not isinstance(randomizer, DomainRandomizer) and randomizer is not None:
-            raise TypeErr(given=randomizer, expected_type=DomainRandomizer)
+        _require(inner_env(wrapped_env), SimEnv)
+        self._randomizer = _require(randomizer, DomainRandomizer, allow_none=True)
         super().__init__(wrapped_env)
-        self._randomizer = randomizer
 
     @property
     def randomizer(self) -> DomainRandomizer:
@@ -29,16 +35,15 @@ class DomainRandWrapper(EnvWrapper):
 
     @randomizer.setter
     def randomizer(self, randomizer: DomainRandomizer):
-        if not isinstance(randomizer, DomainRandomizer):
-            raise TypeErr(given=randomizer, expected_type=DomainRandomizer)
-        self._randomizer = randomizer
+        self._randomizer = _require(randomizer, DomainRandomizer)
 
 
 class MetaDomainRandWrapper(DomainRandWrapper):
+    """ Entry i of a vector sets distribution parameter mapping[i] = (domain parameter, distribution parameter) of the
+    randomizer of the wrapper below (:51-103); the randomizer itself stays with that wrapper. """
+
     def __init__(self, wrapped_rand_env: DomainRandWrapper, mapping: Dict[int, Tuple[str, str]]):
-        if not isinstance(wrapped_rand_env, DomainRandWrapper):
-            raise TypeErr(given=wrapped_rand_env, expected_type=DomainRandWrapper)
-        super().__init__(wrapped_rand_env, None)
+        super().__init__(_require(wrapped_rand_env, DomainRandWrapper), None)
         self.mapping = mapping
 
     @property
@@ -49,72 +54,78 @@ class MetaDomainRandWrapper(DomainRandWrapper):
     def randomizer(self, dr: DomainRandomizer):
         self._wrapped_env.randomizer = dr
 
+    def adapt_randomizer(self, domain_distr_param_values: np.ndarray):
+        target = self._wrapped_env.randomizer
+        for idx, val in enumerate(np.asarray(domain_distr_param_values).ravel()):
+            target.adapt_one_distr_param(*self.mapping.get(idx), val)
+
     def reset(self, init_state: np.ndarray = None, domain_param: dict = None):
         return self._wrapped_env.reset(init_state, domain_param)
-
-    def adapt_randomizer(self, domain_distr_param_values: np.ndarray):
-        for i, value in enumerate(np.asarray(domain_distr_param_values).ravel()):
-            dp_name, ddp_name = self.mapping.get(i)
-            self._wrapped_env.randomizer.adapt_one_distr_param(dp_name, ddp_name, value)
 
 
 class DomainRandWrapperLive(DomainRandWrapper):
+    """ A fresh draw at every reset that is not given parameters (:106-127). """
+
     def reset(self, init_state: np.ndarray = None, domain_param: dict = None):
-        if domain_param is None:
-            self._randomizer.randomize(num_samples=1)
-            domain_param = self._randomizer.get_params(format='dict', dtype='numpy')
-        return self._wrapped_env.reset(init_state, domain_param)
+        if domain_param is not None:
+            return self._wrapped_env.reset(init_state, domain_param)
+        self._randomizer.randomize(num_samples=1)
+        return self._wrapped_env.reset(init_state, self._randomizer.get_params(format='dict', dtype='numpy'))
 
 
 class DomainRandWrapperBuffer(DomainRandWrapper):
+    """ Resets walk round a buffer of parameter sets, filled once (:130-199).  The buffer is a list of dicts, or one dict
+    that every reset uses. """
+
     def __init__(self, wrapped_env, randomizer: DomainRandomizer):
         super().__init__(wrapped_env, randomizer)
-        self._ring_idx = None
-        self._buffer = None
+        self._buffer, self._ring_idx = None, None
 
-    @property
-    def ring_idx(self) -> int:
+    # ring position ------------------------------------------------------------------------------------------------
+    def _get_ring_idx(self) -> int:
         return self._ring_idx
 
-    @ring_idx.setter
-    def ring_idx(self, idx: int):
+    def _set_ring_idx(self, idx: int):
         assert isinstance(idx, (int, np.integer)) and idx >= 0
         self._ring_idx = int(idx)
+
+    ring_idx = property(_get_ring_idx, _set_ring_idx)
+
+    # buffer ---------------------------------------------------------------------------------------------------------
+    def _get_buffer(self):
+        return self._buffer
+
+    def _set_buffer(self, buffer):
+        self._buffer = _require(buffer, (list, dict))
+
+    buffer = property(_get_buffer, _set_buffer)
 
     def fill_buffer(self, num_domains: int):
         assert isinstance(num_domains, int) and num_domains >= 0
         self._randomizer.randomize(num_domains)
-        self._buffer = self._randomizer.get_params(-1, format='list', dtype='numpy')
-        if isinstance(self._buffer, dict):
-            self._buffer = [self._buffer]
+        sets = self._randomizer.get_params(-1, format='list', dtype='numpy')
+        self._buffer = [sets] if isinstance(sets, dict) else sets   # (a single draw comes back as one dict)
         self._ring_idx = 0
 
-    @property
-    def buffer(self):
-        return self._buffer
-
-    @buffer.setter
-    def buffer(self, buffer):
-        if not isinstance(buffer, (list, dict)):
-            raise TypeErr(given=buffer, expected_type=[list, dict])
-        self._buffer = buffer
+    def _next_buffered(self) -> dict:
+        buf = _require(self._buffer, (dict, list))
+        if isinstance(buf, dict):
+            return buf
+        taken, self._ring_idx = buf[self._ring_idx], (self._ring_idx + 1) % len(buf)
+        return taken
 
     def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
         if domain_param is None:
-            if isinstance(self._buffer, dict):
-                domain_param = self._buffer
-            elif isinstance(self._buffer, list):
-                domain_param = self._buffer[self._ring_idx]
-                self._ring_idx = (self._ring_idx + 1) % len(self._buffer)
-            else:
-                raise TypeErr(given=self._buffer, given_name='self._buffer', expected_type=[dict, list])
+            domain_param = self._next_buffered()
         else:
             self._load_domain_param(domain_param)
+        # the parameters go in through the setter, the inner reset then gets none (:193-199)
         self._wrapped_env.domain_param = domain_param
         return self._wrapped_env.reset(init_state, domain_param=None)
 
 
 def remove_all_dr_wrappers(env, verbose: bool = False):
+    """ Strips every randomizing wrapper from the chain (:202-229). """
     while any(isinstance(e, DomainRandWrapper) for e in all_envs(env)):
         env = remove_env(env, DomainRandWrapper)
     return env
