@@ -9,10 +9,14 @@ from .base import EnvWrapperAct
 
 
 class ActNormWrapper(EnvWrapperAct):
-    def _process_act(self, act: np.ndarray) -> np.ndarray:
-        lb, ub = self.wrapped_env.act_space.bounds
-        return lb + (act + 1)*(ub - lb)/2
+    """ The policy sees the unit box; -1 and 1 are the bounds the wrapped environment has at the time of the step (they
+    follow its domain parameters). """
 
     def _process_act_space(self, space: BoxSpace) -> BoxSpace:
-        ub = np.ones(space.shape)
-        return BoxSpace(-ub, ub, labels=space.labels)
+        one = np.ones(space.shape)
+        return BoxSpace(-one, one, labels=space.labels)
+
+    def _process_act(self, act: np.ndarray) -> np.ndarray:
+        lo, hi = self.wrapped_env.act_space.bounds
+        # same order of operations as the reference (:13-15) and the fused kernels: lo + (a + 1) (hi - lo) / 2
+        return lo + (act + 1)*(hi - lo)/2

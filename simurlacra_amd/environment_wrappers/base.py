@@ -11,88 +11,66 @@ from ..environments.sim_base import SimEnv
 from ..utils.exceptions import TypeErr
 
 
+def _forward(attr: str, writable: bool = False) -> property:
+    """ A property that reads (and, if writable, writes) attribute `attr` of the wrapped environment. """
+    def getter(self):
+        return getattr(self._wrapped_env, attr)
+
+    def setter(self, value):
+        setattr(self._wrapped_env, attr, value)
+
+    return property(getter, setter if writable else None, doc=f'`{attr}` of the wrapped environment')
+
+
 class EnvWrapper(Env):
+    """ Hands the whole Env interface down to the environment it wraps (:13-168); subclasses intercept what they change.
+    Domain parameters pass two hooks on their way down and up, so that a wrapper can keep entries of its own in the dict. """
+
     def __init__(self, wrapped_env: Env):
         if not isinstance(wrapped_env, Env):
             raise TypeErr(given=wrapped_env, expected_type=Env)
         self._wrapped_env = wrapped_env
 
-    @property
-    def name(self) -> str:
-        return self._wrapped_env.name
-
-    @property
-    def wrapped_env(self):
-        return self._wrapped_env
-
-    @property
-    def state(self):
-        return self._wrapped_env.state
-
-    @state.setter
-    def state(self, value):
-        self._wrapped_env.state = value
-
-    @property
-    def state_space(self):
-        return self._wrapped_env.state_space
-
-    @property
-    def obs_space(self):
-        return self._wrapped_env.obs_space
-
-    @property
-    def act_space(self):
-        return self._wrapped_env.act_space
+    wrapped_env = property(lambda self: self._wrapped_env)
+    name = _forward('name')
+    state = _forward('state', writable=True)
+    state_space = _forward('state_space')
+    obs_space = _forward('obs_space')
+    act_space = _forward('act_space')
+    dt = _forward('dt', writable=True)
+    curr_step = _forward('curr_step')
+    max_steps = _forward('max_steps', writable=True)
+    task = _forward('task')
+    supported_domain_param = _forward('supported_domain_param')
 
     @property
     def init_space(self):
-        if isinstance(self._wrapped_env, (SimEnv, EnvWrapper)):
-            return self._wrapped_env.init_space
-        raise NotImplementedError
+        if not isinstance(self._wrapped_env, (SimEnv, EnvWrapper)):   # only simulations have one (:61-67)
+            raise NotImplementedError
+        return self._wrapped_env.init_space
 
-    @property
-    def dt(self):
-        return self._wrapped_env.dt
+    # domain parameters: hooks first on the way down, last on the way up ----------------------------------------------
+    def _load_domain_param(self, param: dict):
+        """ Called with the dict that is about to be set: take this wrapper's entries out of it. """
 
-    @dt.setter
-    def dt(self, dt):
-        self._wrapped_env.dt = dt
-
-    @property
-    def curr_step(self) -> int:
-        return self._wrapped_env.curr_step
-
-    @property
-    def max_steps(self):
-        return self._wrapped_env.max_steps
-
-    @max_steps.setter
-    def max_steps(self, num_steps):
-        self._wrapped_env.max_steps = num_steps
-
-    @property
-    def task(self):
-        return self._wrapped_env.task
+    def _save_domain_param(self, param: dict):
+        """ Called with the dict that is about to be returned: put this wrapper's entries into it. """
 
     @property
     def domain_param(self) -> dict:
-        param = self._wrapped_env.domain_param
-        self._save_domain_param(param)
-        return param
+        collected = self._wrapped_env.domain_param
+        self._save_domain_param(collected)
+        return collected
 
     @domain_param.setter
     def domain_param(self, param: dict):
         self._load_domain_param(param)
         self._wrapped_env.domain_param = param
 
-    @property
-    def supported_domain_param(self):
-        return self._wrapped_env.supported_domain_param
-
     def get_nominal_domain_param(self):
         return self._wrapped_env.get_nominal_domain_param()
 
+    # stepping ---------------------------------------------------------------------------------------------------------
     def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
         if domain_param is not None:
             self._load_domain_param(domain_param)
@@ -110,14 +88,10 @@ class EnvWrapper(Env):
     def close(self):
         return self._wrapped_env.close()
 
-    def _load_domain_param(self, param: dict):
-        pass
-
-    def _save_domain_param(self, param: dict):
-        pass
-
 
 class EnvWrapperAct(EnvWrapper):
+    """ Changes the action on its way into step(), and the action space with it (:171-199). """
+
     @abstractmethod
     def _process_act(self, act: np.ndarray):
         raise NotImplementedError
@@ -125,15 +99,15 @@ class EnvWrapperAct(EnvWrapper):
     def _process_act_space(self, space):
         return space
 
-    def step(self, act: np.ndarray) -> tuple:
-        return super().step(self._process_act(act))
+    act_space = property(lambda self: self._process_act_space(super(EnvWrapperAct, self).act_space))
 
-    @property
-    def act_space(self):
-        return self._process_act_space(super().act_space)
+    def step(self, act: np.ndarray) -> tuple:
+        return super().step(self._process_act(act))   # (cooperative: a wrapper may be both kinds, e.g. DownsamplingWrapper)
 
 
 class EnvWrapperObs(EnvWrapper):
+    """ Changes the observation on its way out of reset() and step(), and the observation space with it (:202-231). """
+
     @abstractmethod
     def _process_obs(self, obs: np.ndarray):
         raise NotImplementedError
@@ -141,13 +115,11 @@ class EnvWrapperObs(EnvWrapper):
     def _process_obs_space(self, space):
         return space
 
-    @property
-    def obs_space(self):
-        return self._process_obs_space(super().obs_space)
+    obs_space = property(lambda self: self._process_obs_space(super(EnvWrapperObs, self).obs_space))
 
     def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
         return self._process_obs(super().reset(init_state, domain_param))
 
     def step(self, act: np.ndarray) -> tuple:
-        obs, rew, done, info = super().step(act)
-        return self._process_obs(obs), rew, done, info
+        out = super().step(act)
+        return (self._process_obs(out[0]),) + tuple(out[1:])

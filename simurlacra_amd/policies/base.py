@@ -13,22 +13,25 @@ from ..utils.exceptions import ShapeErr, TypeErr
 
 
 class Policy(nn.Module, ABC):
+    """ What the samplers need from a policy: its specification, a flat view of its parameters, forward(); and, for the
+    fused rollout kernels, a description of itself (fused_spec). """
     name: str = None
 
     def __init__(self, spec: EnvSpec, use_cuda: bool = False):
-        super().__init__()
         if not isinstance(spec, EnvSpec):
             raise TypeErr(given=spec, expected_type=EnvSpec)
+        nn.Module.__init__(self)
         self._env_spec = spec
-        self._device = 'cuda' if use_cuda and to.cuda.is_available() else 'cpu'
+        self._device = 'cuda' if (use_cuda and to.cuda.is_available()) else 'cpu'
 
-    @property
-    def device(self) -> str:
-        return self._device
+    env_spec = property(lambda self: self._env_spec)
+    device = property(lambda self: self._device)
+    is_recurrent = property(lambda self: False)
 
+    # the parameters as one vector (:58-75) ----------------------------------------------------------------------------
     @property
-    def env_spec(self) -> EnvSpec:
-        return self._env_spec
+    def num_param(self) -> int:
+        return sum(p.data.numel() for p in self.parameters())
 
     @property
     def param_values(self) -> to.Tensor:
@@ -36,33 +39,29 @@ class Policy(nn.Module, ABC):
 
     @param_values.setter
     def param_values(self, param: to.Tensor):
-        if not self.param_values.shape == param.shape:
-            raise ShapeErr(given=param, expected_match=self.param_values)
-        cp.vector_to_parameters(param.to(self.param_values.dtype), self.parameters())
+        current = self.param_values
+        if param.shape != current.shape:
+            raise ShapeErr(given=param, expected_match=current)
+        cp.vector_to_parameters(param.to(current.dtype), self.parameters())
 
-    @property
-    def num_param(self) -> int:
-        return sum(p.data.numel() for p in self.parameters())
-
-    @property
-    def is_recurrent(self) -> bool:
-        return False
-
+    # what subclasses provide ------------------------------------------------------------------------------------------
     @abstractmethod
     def init_param(self, init_values: to.Tensor = None, **kwargs):
         raise NotImplementedError
-
-    def reset(self):
-        pass
 
     @abstractmethod
     def forward(self, obs: to.Tensor) -> to.Tensor:
         raise NotImplementedError
 
+    def reset(self):
+        """ Nothing to reset in a feed-forward policy. """
+
     def evaluate(self, rollout, hidden_states_name: str = 'hidden_states') -> to.Tensor:
+        """ The actions for all observations of a rollout but the last (:131-156, feed-forward case). """
         self.eval()
         return self(rollout.get_data_values('observations', truncate_last=True))
 
+    # the fused path ---------------------------------------------------------------------------------------------------
     def fused_spec(self):
         """ Description of this policy for the fused rollout kernels, or None when it has to be evaluated step by
         step through torch. """
