@@ -133,6 +133,40 @@ def test_qbb_ik_c_vs_numpy():
 
 
 # ----------------------------------------------------------------------------------- C vs NumPy restatement
+@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB, abi.ENV_OMO, abi.ENV_QCP_ST, abi.ENV_BOB])
+def test_infinite_state_components_give_nan_rewards_in_both_restatements(kind):
+    """ The quadratic cost is err.dot(Q).dot(err) (rewards.py:67-72): an infinite error component meets the zeros of Q's
+    other rows, and 0 * inf is a NaN -- in NumPy's products as in the C restatement's full sums.  The kernels for the
+    default (diagonal) task are held to this in tests/test_gpu_parity.py::test_nan_and_infinite_initial_states.
+    OneMassOscillator's dynamics are A.dot(state) + B.dot(act) (one_mass_oscillator.py:80-85): an infinite position makes
+    the new position a NaN the same way. """
+    name = cases.KIND_NAMES[kind]
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    nom = envdefs.nominal_domain_param(kind)
+    dp = np.array(list(nom.values()), dtype=float)
+    task_c = envdefs.default_task_spec(kind).to_c(S, A)
+    for comp in range(S):
+        for bad in (np.inf, -np.inf):
+            state = 0.01*np.arange(1, S + 1, dtype=float)
+            state[comp] = bad
+            env = onp.NpEnv(name, cases.DT[kind], 10)
+            env.reset(0.01*np.arange(1, (4 if kind == abi.ENV_QBB else S) + 1, dtype=float), dict(nom))
+            with np.errstate(all='ignore'):
+                r_np = env.task.step_rew(state.copy(), np.zeros(A))
+            r_c = orc.step_rew(kind, task_c, dp, state, np.zeros(A))
+            assert np.isnan(r_np) and np.isnan(r_c), (name, comp, bad, r_np, r_c)
+    if kind == abi.ENV_OMO:
+        env = onp.NpEnv(name, cases.DT[kind], 10)
+        env.reset(np.array([0.1, 0.2]), dict(nom))
+        env.state = np.array([np.inf, 0.2])
+        with np.errstate(all='ignore'):
+            env._dynamics(np.zeros(1))
+        assert np.isnan(env.state[0]) and np.isinf(env.state[1])
+        mem = orc.reset(kind, cases.DT[kind], 10, task_c, np.array([[np.inf], [0.2]]), dp.reshape(-1, 1))
+        obs, rew, done, status, _ = orc.step(kind, cases.DT[kind], 10, task_c, mem, np.zeros((1, 1)), dp.reshape(-1, 1))
+        assert np.isnan(mem['state'][0, 0]) and np.isinf(mem['state'][1, 0]) and done[0] and (status[0] & abi.ST_NAN) and np.isnan(rew[0])
+
+
 @pytest.mark.parametrize('kind', cases.KINDS)
 @pytest.mark.parametrize('pol', ['linear', 'fnn'])
 def test_c_and_numpy_restatements_agree(kind, pol):
