@@ -64,6 +64,9 @@ constexpr int TASK_DOUBLES = (sizeof(psh_task) + sizeof(psh_wrappers)) / 8;
 // row sum (+ |bias|) stays below FNN_GAIN_LIMIT keep every pre-activation finite and below 2^40, where the table split of
 // the tanh is exact without any clamp.
 constexpr double FNN_OBS_LIMIT = 1048576.0, FNN_GAIN_LIMIT = 524288.0;   // 2^20, 2^19
+// Behind the packed weight image: [0..3] the per-layer bounds of k_fnn_bounds, [4..11] the largest |weight| of each input
+// column of the first layer, [12] its largest |bias| (see k_fnn_bounds), the rest unused.
+constexpr int FNN_TAIL = 16;
 constexpr double FNN_BOUND_LIMIT = 19.9;   // k_fnn_bounds: the tanh table ends at 20; the margin covers the rounding of the sums
 constexpr int TANH8_PAD = (PSH_TANH8_N + 1) / 2 * 2, TANH_TAB_PAD = (PSH_TANH_TAB_N + 1) / 2 * 2, TANH_ODD_PAD = (PSH_TANH_ODD_N + 1) / 2 * 2;
 
@@ -981,9 +984,9 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
     // trip in front of every layer's activations)
     int bounded_layers = 0;
     if constexpr (!POP) {
-        for (int l = 1; l < n_hidden; ++l) bounded_layers |= (w_lds[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT ? 1 : 0) << l;
+        for (int l = 1; l < n_hidden; ++l) bounded_layers |= (w_lds[a.lds_doubles - FNN_TAIL + l] <= FNN_BOUND_LIMIT ? 1 : 0) << l;
         // bit 0: every weight of the hidden layers is finite and the first layer's gain is moderate (k_fnn_bounds)
-        bounded_layers |= w_lds[a.lds_doubles - 4] <= FNN_GAIN_LIMIT ? 1 : 0;
+        bounded_layers |= w_lds[a.lds_doubles - FNN_TAIL] <= FNN_GAIN_LIMIT ? 1 : 0;
         bounded_layers = __builtin_amdgcn_readfirstlane(bounded_layers);
     }
     for (;;) {
@@ -1067,12 +1070,25 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
         // every observation of the wave is finite and moderate (lanes without an environment hold zeros) and the policy's
         // weights are (checked once, when they were packed), the activations run without clamp and NaN bookkeeping; any
         // other step takes the careful forms.
-        bool obs_ok = true;
-        if constexpr (TANH && FINE) {
-            bool big = false;
+        // One policy: with the largest |weight| per input column of the first layer (k_fnn_bounds) the wave bounds this
+        // step's first-layer pre-activations from the observations it holds.  Inside the tanh table's range they need no
+        // limit on the table index either (the common case: 16 -> 15 instructions per activation of the first layer), and
+        // the test covers the one below (a NaN or an infinity anywhere fails it).
+        bool obs_ok = true, tight0 = false;
+        if constexpr (TANH && FINE && !POP) {
+            const double* const tail = w_lds + (a.lds_doubles - FNN_TAIL);
+            double b0 = tail[12];
 #pragma unroll
-            for (int r = 0; r < E::O; ++r) big = big || !(fabs(obs[r]) < FNN_OBS_LIMIT);
-            obs_ok = !__any(big);
+            for (int r = 0; r < E::O; ++r) b0 = fma(fabs(obs[r]), tail[4 + r], b0);
+            tight0 = (bounded_layers & 1) != 0 && !__any(!(b0 <= FNN_BOUND_LIMIT));
+        }
+        if constexpr (TANH && FINE) {
+            if (!tight0) {
+                bool big = false;
+#pragma unroll
+                for (int r = 0; r < E::O; ++r) big = big || !(fabs(obs[r]) < FNN_OBS_LIMIT);
+                obs_ok = !__any(big);
+            }
         }
         // stage the observations: row r of this wave's staging area holds obs[r] of its 64 envs
 #pragma unroll
@@ -1089,7 +1105,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
             // are left, then costs a quarter per step; population tasks with fewer than 64 rollouts)
             if (((live_mask >> (16 * tile)) & 0xFFFFull) == 0) return;
             const double* const wimg = POP ? w_lds + (tile >> pop_shift) * a.lds_doubles : w_lds;  // of this tile's policy
-            const bool fast = TANH && FINE && obs_ok && (POP ? wimg[a.lds_doubles - 4] <= FNN_GAIN_LIMIT : (bounded_layers & 1) != 0);
+            const bool fast = TANH && FINE && obs_ok && (POP ? wimg[a.lds_doubles - FNN_TAIL] <= FNN_GAIN_LIMIT : (bounded_layers & 1) != 0);
             double y[KS];
             // layer 0
             {
@@ -1117,7 +1133,9 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[r];
                 }
-                if (fast)
+                if (!POP && tight0)
+                    nl_apply_all<KS, FINE, LV2>((int)PSH_NL_TANH, y, tanh_tab);
+                else if (fast)
                     nl_apply_all<KS, FINE, LV1>((int)PSH_NL_TANH, y, tanh_tab);
                 else
                     nl_apply_all<KS, FINE>(TANH ? (int)PSH_NL_TANH : a.pol.hidden_nonlin[0], y, tanh_tab);
@@ -1145,7 +1163,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                 for (int t = 0; t < HT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[4 * t + r] = acc[t][r];
-                if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
+                if (wimg[a.lds_doubles - FNN_TAIL + 1] <= FNN_BOUND_LIMIT) {
                     if (fast) nl_apply_all<KS, FINE, LV2>((int)PSH_NL_TANH, y, tanh_tab);
                     else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
                 } else {
@@ -1183,7 +1201,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                 // behind a tanh layer the inputs lie in [-1, 1]: if the weights of this layer keep every pre-activation
                 // below the table's end (row sums of |W| plus |b|, computed by k_fnn_bounds), the clamp and the NaN
                 // bookkeeping of the activation are not needed
-                if (TANH && FINE && (POP ? wimg[a.lds_doubles - 4 + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0)) {
+                if (TANH && FINE && (POP ? wimg[a.lds_doubles - FNN_TAIL + l] <= FNN_BOUND_LIMIT : ((bounded_layers >> l) & 1) != 0)) {
                     if (fast) nl_apply_all<KS, FINE, LV2>((int)PSH_NL_TANH, y, tanh_tab);
                     else nl_apply_all<KS, FINE, 1>((int)PSH_NL_TANH, y, tanh_tab);
                 } else {
@@ -1357,7 +1375,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                 if (((live_mask >> (16 * p)) & 0xFFFFull) == 0) return;
                 constexpr int NG = (WREG == 4 || WREG == 6) ? 1 : 2;   // column groups of 4 rollouts
                 const double* const wimg = w_lds + p * a.lds_doubles;
-                const bool fast = obs_ok && wimg[a.lds_doubles - 4] <= FNN_GAIN_LIMIT;
+                const bool fast = obs_ok && wimg[a.lds_doubles - FNN_TAIL] <= FNN_GAIN_LIMIT;
                 const int h = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
                 const int unit = 4 * b + h;          // + 16 rs
                 const int env_lane = 16 * p + l;     // + 4 g
@@ -1433,7 +1451,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
                         for (int rs = 0; rs < HT; ++rs) y[g][rs] = acc[rs][g];
-                    if (wimg[a.lds_doubles - 4 + 1] <= FNN_BOUND_LIMIT) {
+                    if (wimg[a.lds_doubles - FNN_TAIL + 1] <= FNN_BOUND_LIMIT) {
                         if (fast) {
 #pragma unroll
                             for (int g = 0; g < NG; ++g) nl_apply_all<HT, FINE, 2>((int)PSH_NL_TANH, y[g], tanh_tab);
@@ -1509,7 +1527,7 @@ __global__ __launch_bounds__(WREG ? (HP == 64 && WREG < 5 ? 256 : 512) : ((WRAP 
 static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restrict__ params, double* __restrict__ out, int total, int O,
                                                    int A, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
     params += (long)blockIdx.x * num_param;
-    out += (long)blockIdx.x * total + (total - 4);
+    out += (long)blockIdx.x * total + (total - FNN_TAIL);
     const int hs[4] = {h0, h1, h2, h3};
     const int u = threadIdx.x;
     int poff = 0, last = O;
@@ -1541,6 +1559,21 @@ static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restri
     }
     // entry 0: the first layer's bound per unit of observation, infinite unless EVERY hidden layer's weights are finite
     if (u == 0) out[0] = all_finite ? first : __builtin_inf();
+    // entries 4.., 12: per input column the largest |weight| of the first layer, and its largest |bias|: with them a wave
+    // bounds its first-layer pre-activations from the observations it holds, |y| <= sum_r colmax[r] |obs[r]| + bmax
+    // (a NaN or infinite weight gives a NaN or infinite entry, which fails the kernel's comparison)
+    const int h = hs[0];
+    for (int r = 0; r <= O && r <= 8; ++r) {
+        double m = 0.;
+        if (u < h) m = fabs(r < O ? params[u * O + r] : params[h * O + u]);
+        bool bad = m != m;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(m, o);
+            m = other > m ? other : m;
+        }
+        if (__any(bad)) m = __builtin_nan("");
+        if (u == 0) out[r < O ? 4 + r : 12] = m;
+    }
 }
 
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
@@ -1765,8 +1798,8 @@ template <int KIND> int launch_rollout(psh_ctx* c, const psh_rollout_desc* d, Ro
     }
     const int HP = hmax <= 16 ? 16 : (hmax <= 32 ? 32 : 64);
     const int OP = (E::O + 3) / 4 * 4, HT = HP / 16, KS = HP / 4, K0 = E::O / 4, REM = E::O % 4;
-    // the image: weight fragments, biases, output layer (2 doubles of bias), 4 doubles of per-layer bounds
-    const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2 + 4;
+    // the image: weight fragments, biases, output layer (2 doubles of bias), FNN_TAIL doubles of bounds
+    const int total = HT * K0 * 64 + REM * HP + HP + (p.n_hidden - 1) * (HT * KS * 64 + HP) + E::A * HP + 2 + FNN_TAIL;
     double* wfrag = nullptr;
     {
         const int rc = scratch_doubles(c, PSH_SCR_WFRAG, (size_t)total * (per_env ? p.n_policies : 1), &wfrag);
