@@ -450,7 +450,8 @@ int psh_bootstrap_means(psh_ctx* ctx, int32_t n, int32_t num_reps, const double*
 /* Diagnostic, no counterpart in the reference: evaluates one of the device's fp64 elementary functions
  * (the ones the step loop uses in place of NumPy's np.exp / np.tanh / np.sin / np.cos / np.fmod) element-wise, so that
  * their accuracy can be tested directly.  fn: 0 exp, 1 tanh (exponential form), 2 sigmoid, 3 sin, 4 cos,
- * 5 fmod(x[i], m[i]), 6 / 7 tanh from the fine / coarse lookup table (the forms the FNNPolicy kernels use). */
+ * 5 fmod(x[i], m[i]), 6 / 7 tanh from the fine / coarse lookup table (the forms the FNNPolicy kernels use), 8 log (the
+ * swing-up reward's and the Box-Muller draws'). */
 int psh_eval_math(psh_ctx* ctx, int32_t fn, int32_t n, const double* x /*[dev][n]*/, const double* m /*[dev][n] or NULL*/,
                   double* y /*[dev][n]*/, void* stream);
 

@@ -490,7 +490,7 @@ PSH_DEV double step_rew(const psh_task& t, double c_max, const double* state, co
             eth = (i == (FIXT ? 1 : t.idx_th)) ? es[i] : eth;
             ex = (i == (FIXT ? 0 : t.idx_x)) ? es[i] : ex;
         }
-        const double cost_pole = t.swingup[3] * (eth * eth) + log(eth * eth + t.swingup[4]);
+        const double cost_pole = t.swingup[3] * (eth * eth) + psh_log(eth * eth + t.swingup[4]);
         return -t.swingup[0] * cost_pole - t.swingup[1] * fabs(ex) - t.swingup[2] * (ea[0] * ea[0]) + 10;
     }
     // FIXT takes Q and R as diagonal.  The reference multiplies the full matrices (rewards.py:67-72: err.dot(Q).dot(err)), and

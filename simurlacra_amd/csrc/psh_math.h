@@ -121,6 +121,35 @@ PSH_MATH double psh_exp(double x) {
     return psh_exp_core(x);
 }
 
+// log for a positive, normal, finite x; anything else takes the library routine.  The library's log carries a
+// double-double reduction for its last half ulp (about 100 vector instructions); this is the classic scheme in plain
+// doubles (about 35): x = 2^k m with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log m = f - f^2/2 +
+// s (f^2/2 + R(s^2)) with the 7-term minimax polynomial R of the Sun/fdlibm kernel (truncation below 2^-58), log 2 in
+// two parts.  Within 1 ulp.
+PSH_MATH double psh_log_normal(double x) {   // x positive, normal and finite
+    double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 7.07106781186547524401e-01;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double dk = (double)k;
+    const double f = m - 1.0;
+    const double s = psh_div_moderate(f, 2.0 + f);   // the denominator lies in [1.70, 2.42)
+    const double z = s * s, w = z * z;
+    double t1 = fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);   // Lg6, Lg4
+    t1 = psh_horner(t1, w, 3.999999999940941908e-01);                          // Lg2
+    double t2 = fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);   // Lg7, Lg5
+    t2 = psh_horner(t2, w, 2.857142874366239149e-01);                          // Lg3
+    t2 = psh_horner(t2, w, 6.666666666666735130e-01);                          // Lg1
+    const double R = fma(t2, z, t1 * w);
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+PSH_MATH double psh_log(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.79e308)) return log(x);
+    return psh_log_normal(x);
+}
+
 PSH_MATH double psh_tanh(double x) {
     const double a = fabs(x);
     double y = -2.0 * a;
@@ -257,11 +286,7 @@ PSH_MATH double psh_sigmoid(double x) {
 
 // sin and cos together.  Cody-Waite reduction by pi/2 in three parts, exact for |x| <= 1e5; larger or non-finite
 // arguments take the library path.
-PSH_MATH void psh_sincos(double x, double* s, double* c) {
-    if (!(fabs(x) <= 1.0e5)) {
-        sincos(x, s, c);
-        return;
-    }
+PSH_MATH void psh_sincos_moderate(double x, double* s, double* c) {   // |x| <= 1e5
     int n;
     const double nd = psh_round_scaled(x, 6.36619772367581382433e-01, n);  // 2/pi
     double r = fma(-nd, 1.57079632673412561417e+00, x);      // pi/2, first 33 bits
@@ -289,6 +314,13 @@ PSH_MATH void psh_sincos(double x, double* s, double* c) {
     // quadrants 2, 3 negate the sine and quadrants 1, 2 the cosine: bit 1 of n (of n + 1) moved onto the sign bit
     *s = __hiloint2double(__double2hiint(ss) ^ (int)(((unsigned)n << 30) & 0x80000000u), __double2loint(ss));
     *c = __hiloint2double(__double2hiint(cc) ^ (int)(((unsigned)(n + 1) << 30) & 0x80000000u), __double2loint(cc));
+}
+PSH_MATH void psh_sincos(double x, double* s, double* c) {
+    if (!(fabs(x) <= 1.0e5)) {
+        sincos(x, s, c);
+        return;
+    }
+    psh_sincos_moderate(x, s, c);
 }
 
 // C fmod (sign of x, exact) for quotients below 2^52; library path otherwise

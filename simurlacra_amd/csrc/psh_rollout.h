@@ -135,8 +135,8 @@ template <int N> PSH_DEV void step_normals(uint64_t seed, uint64_t env, uint32_t
     for (int p = 0; 2 * p < N; ++p) {
         double ua, ub, sn, cs;
         psh_draw2(seed, env, t, stream + 16u * p, ua, ub);
-        const double r = sqrt(-2.0 * log(1.0 - ua));
-        psh_sincos(2.0 * PSH_PI * ub, &sn, &cs);  // (the argument lies in [0, 2 pi): the reduction's fast range)
+        const double r = sqrt(-2.0 * psh_log_normal(1.0 - ua));   // (1 - ua lies in [2^-53, 1])
+        psh_sincos_moderate(2.0 * PSH_PI * ub, &sn, &cs);  // (the argument lies in [0, 2 pi))
         out[2 * p] = r * cs;
         if (2 * p + 1 < N) out[2 * p + 1] = r * sn;
     }

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void k_eval_math(int fn, int n, const double* 
         y[i] = hi > PSH_HI_INF ? x[i] : r;
         break;
     }
+    case 8: y[i] = psh_log(x[i]); break;
     default: y[i] = psh_fmod(x[i], m[i]);
     }
 }
@@ -683,7 +684,7 @@ extern "C" int psh_bootstrap_means(psh_ctx* c, int32_t n, int32_t num_reps, cons
 }
 
 extern "C" int psh_eval_math(psh_ctx* c, int32_t fn, int32_t n, const double* x, const double* m, double* y, void* stream) {
-    if (!c || fn < 0 || fn > 7 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
+    if (!c || fn < 0 || fn > 8 || n < 0 || (n > 0 && (!x || !y || (fn == 5 && !m)))) { set_err(c, "invalid math-evaluation arguments"); return PSH_ERR_ARG; }
     if (n == 0) return PSH_OK;
     PSH_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_eval_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)fn, (int)n, x, m, y, (const double*)c->tanh_tab);

@@ -239,8 +239,8 @@ class Engine:
         return ang
 
     def eval_math(self, fn: str, x, m=None):
-        """ Element-wise device math (diagnostic): fn in exp, tanh, sigmoid, sin, cos, fmod. """
-        ids = dict(exp=0, tanh=1, sigmoid=2, sin=3, cos=4, fmod=5, tanh_table_fine=6, tanh_table_coarse=7)
+        """ Element-wise device math (diagnostic): fn in exp, tanh, sigmoid, sin, cos, fmod, log. """
+        ids = dict(exp=0, tanh=1, sigmoid=2, sin=3, cos=4, fmod=5, tanh_table_fine=6, tanh_table_coarse=7, log=8)
         x = self.f64(x).reshape(-1)
         m = None if m is None else self.f64(m).reshape(-1)
         y = torch.empty_like(x)

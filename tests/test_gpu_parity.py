@@ -887,6 +887,17 @@ def test_device_math_accuracy(eng):
         got = eng.eval_math(fn, nan_in).cpu().numpy()
         assert np.isnan(got[0]) and got[1] == 1. and got[2] == -1., fn
     assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
+    # log: the swing-up reward's argument range, the Box-Muller draws' (0, 1], the whole exponent range, and the
+    # arguments the fast path hands to the library
+    x = np.concatenate([rng.uniform(0.1, 10.2, 20000), 1. - rng.random(20000), 2.**rng.uniform(-1000, 1000, 20000),
+                        1. + rng.uniform(-1e-3, 1e-3, 5000), [1., 0.5, 2., np.sqrt(0.5), np.sqrt(2.), 2.**-53, 1e-310, 1e308]])
+    got, ref = eng.eval_math('log', x).cpu().numpy(), np.log(x)
+    nz = ref != 0
+    assert _ulp_err(got[nz], ref[nz]).max() <= 1.5 and np.all(got[~nz] == 0)
+    with np.errstate(all='ignore'):
+        odd = np.array([0., -1., np.inf, np.nan])
+        got = eng.eval_math('log', odd).cpu().numpy()
+    assert got[0] == -np.inf and np.isnan(got[1]) and got[2] == np.inf and np.isnan(got[3])
 
 
 @pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB], ids=['qq', 'qbb'])
