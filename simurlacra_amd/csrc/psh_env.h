@@ -453,7 +453,7 @@ template <int KIND, bool FIXT = false> PSH_DEV double task_c_max(const Env<KIND>
     for (int i = 0; i < S; ++i) om[i] = fmax(fabs(lo[i]), fabs(hi[i]));
 #pragma unroll
     for (int i = 0; i < A; ++i) am[i] = fmax(fabs(alo[i]), fabs(ahi[i]));
-    return -1.0 * log(t.min_rew) / (FIXT ? quadr_cost_diag<S, A>(t, om, am) : quadr_cost<S, A>(t, om, am));
+    return -1.0 * psh_log(t.min_rew) / (FIXT ? quadr_cost_diag<S, A>(t, om, am) : quadr_cost<S, A>(t, om, am));
 }
 
 template <int KIND, bool FIXT = false>
