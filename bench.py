@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=2)   # (the first two launches of a process run 2-3 % slower)
     ap.add_argument('--sets', type=int, default=8, help='domain-parameter sets per GPU')
     ap.add_argument('--rollouts', type=int, default=262144, help='rollouts per domain-parameter set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -232,6 +232,7 @@ def main(argv=None):
     # dominant kernel: the rollout launches of the K timed steps themselves (rank 0's), each bracketed by HIP events on
     # the launch stream inside the library; read back only now, so the timed region ran without a host wait in it
     k_all = [eng.rollout_ms(back) for back in range(min(args.steps, 64))]
+    if os.environ.get("PSH_BENCH_VERBOSE"): print("kernel ms, newest first:", [round(v, 2) for v in k_all], file=sys.stderr)
     assert all(v > 0. for v in k_all), k_all
     k_ms = float(np.mean(k_all))
     steps_k = local_steps/args.steps                      # env-steps of one launch, mean over the same launches
