@@ -2,7 +2,7 @@
 """
 Headline benchmark: domain-randomized env-steps/sec (QQube, FNN policy) on N MI355X.
 
-Workload (per GPU, weak scaling): the QQube sweep of BASELINE.json configs[4] — `--sets` domain-parameter sets
+Workload (per GPU, weak scaling): the QQube parameter sweep (8 domain-parameter sets per GPU) — `--sets` domain-parameter sets
 (randomizer distributions whose Mp/Mr/Lp/Lr means and stds are perturbed within +-30 % of the default randomizer)
 x `--rollouts` rollouts each, QQubeSim dt = 1/500, T = 600, FNNPolicy 6-64-64-1 tanh with the reference's
 initialisation (orthogonal weights, N(0,1) biases, seed 0).  One "step" = one pass of the hot path over that batch:
@@ -419,7 +419,7 @@ def cpu_baseline(eng, sets, task_c, ps, params, target_s=12.0):
 
 
 def reference_style_baseline(workers, target_s=5.0):
-    """ BASELINE configs[0] in the reference's cost model (Pyrado/pyrado/sampling/parallel_sampler.py:104-123,
+    """ The smallest workload (1 000 QQube rollouts with a LinearPolicy) in the reference's cost model (Pyrado/pyrado/sampling/parallel_sampler.py:104-123,
     sampler_pool.py:286-418): rollouts spread over a pool of worker processes, each stepping a NumPy environment in the
     interpreter.  Runs as a child process of its own (tools/np_pool_baseline.py): its pool forks, which a process
     holding a GPU context must not do. """

@@ -434,7 +434,7 @@ def test_nan_raises_like_the_reference():
 
 @pytest.mark.parametrize('policy', ['linear', 'fnn16', 'fnn64'])
 def test_cem_generation_on_randomized_qbb_matches_the_oracle(policy):
-    """ The CEM workload of BASELINE configs[3] as a caller writes it: QBallBalancerSim behind ActNormWrapper and
+    """ The CEM workload (a population of policies on randomized QBallBalancer) as a caller writes it: QBallBalancerSim behind ActNormWrapper and
     ActDelayWrapper, the default randomizer plus a per-rollout 'act_delay' drawn from {0..10}
     (Pyrado/scripts/training/qbb_spota_hc.py:29-38), a population of 256 policy-parameter sets x 8 shared (domain
     parameter, initial state) pairs through ParameterExplorationSampler.sample

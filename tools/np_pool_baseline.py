@@ -59,8 +59,8 @@ if __name__ == '__main__':
         el = time.perf_counter() - t0
     if args.json:
         print(json.dumps({'value': steps/el, 'unit': 'env-steps/s', 'cores': workers, 'kind': 'port',
-                          'sample': f'{n} rollouts of QQubeSim (dt 1/500, T 600) + default randomizer + LinearPolicy(identity) '
-                                    f'(BASELINE configs[0]), {steps} env-steps in {el:.1f} s, NumPy restatement stepped in the '
+                          'sample': f'{n} rollouts of QQubeSim (dt 1/500, T 600) + default randomizer + LinearPolicy(identity)'
+                                    f', {steps} env-steps in {el:.1f} s, NumPy restatement stepped in the '
                                     f'interpreter by {workers} worker processes'}))
     else:
         print(f'{steps/el:.1f} env-steps/s with {workers} worker processes ({n} rollouts, {steps} steps, {el:.1f} s)')
