@@ -466,7 +466,7 @@ static double env_step(orc_env* e, const psh_task* t, double* act_io, double dt,
 static double nonlin(int k, double x) {
     switch (k) {
     case PSH_NL_TANH: return tanh(x);
-    case PSH_NL_RELU: return x > 0. ? x : 0.;
+    case PSH_NL_RELU: return !(x <= 0.) ? x : 0.;   /* a NaN stays a NaN, as in torch.relu */
     case PSH_NL_SIGMOID: return 1. / (1. + exp(-x));
     }
     return x;

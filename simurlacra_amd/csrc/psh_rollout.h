@@ -89,7 +89,7 @@ __device__ __forceinline__ void stage_task(const RolloutArgs& a, double* dst) {
 PSH_DEV double nl_apply(int nl, double v) {
     switch (nl) {
     case PSH_NL_TANH: return psh_tanh(v);
-    case PSH_NL_RELU: return v > 0. ? v : 0.;
+    case PSH_NL_RELU: return !(v <= 0.) ? v : 0.;   // a NaN stays a NaN, as in torch.relu
     case PSH_NL_SIGMOID: return psh_sigmoid(v);
     default: return v;
     }
@@ -868,7 +868,7 @@ template <int N, bool FINE, int BOUNDED = 0> PSH_DEV void nl_apply_all(int nl, d
         for (int m = 0; m < N; ++m) y[m] = psh_sigmoid(y[m]);
     } else if (nl == PSH_NL_RELU) {
 #pragma unroll
-        for (int m = 0; m < N; ++m) y[m] = y[m] > 0. ? y[m] : 0.;
+        for (int m = 0; m < N; ++m) y[m] = !(y[m] <= 0.) ? y[m] : 0.;   // a NaN stays a NaN, as in torch.relu
     }
 }
 

@@ -195,3 +195,26 @@ def test_policy_forward_alone_other_nonlinearities(eng, orc, nonlin, out_nonlin)
     obs, act = out['obs'][0].cpu().numpy(), out['act'][0].cpu().numpy()
     want = _torch_fnn(obs.T, params, [O, 64, 32, A], nonlin, out_nonlin).T
     assert np.max(np.abs(act - want)/np.maximum(1., np.abs(want))) <= 1e-12
+
+
+@pytest.mark.parametrize('hidden', [(64, 64), (20, 7)], ids=str)
+@pytest.mark.parametrize('nonlin', ['tanh', 'relu', 'sigmoid', None], ids=str)
+def test_a_nan_weight_reaches_the_action_through_every_activation(eng, orc, nonlin, hidden):
+    """ rollout() stops at a NaN action (sampling/rollout.py:190-201), so a NaN anywhere in the network has to come out of
+    it: torch.relu keeps a NaN, and so must a relu written as a comparison (which by itself answers 0).  A NaN weight in
+    each layer in turn; every rollout ends before its first step with the NaN status, as in the oracle. """
+    kind, n, T = abi.ENV_QCP_SU, 300, 4
+    case = cases.make_case(kind, n, seed=3, policy='fnn', hidden=hidden, nonlin=nonlin)
+    ps = case['ps']
+    sizes = [ps.obs_dim] + list(hidden) + [ps.act_dim]
+    first = np.cumsum([0] + [sizes[l + 1]*sizes[l] + sizes[l + 1] for l in range(len(sizes) - 1)])[:-1]   # W_l[0][0]
+    for l, off in enumerate(first):
+        params = case['params'].copy()
+        params[off + 1] = np.nan   # W_l[0][1]
+        args = (kind, case['dt'], T, case['task_c'], ps, params, case['init'], case['dp'])
+        ref = orc.rollout(*args, record=True)
+        out = {k: v.cpu().numpy() for k, v in eng.rollout(*args, record=True).items()}
+        assert np.all(ref['status'] == abi.ST_NAN) and np.all(ref['length'] == 0), l
+        np.testing.assert_array_equal(out['status'], ref['status'], err_msg=str(l))
+        np.testing.assert_array_equal(out['length'], ref['length'], err_msg=str(l))
+        assert np.all(out['ret'] == 0.) and np.isnan(out['act']).all()

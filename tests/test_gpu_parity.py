@@ -887,6 +887,10 @@ def test_device_math_accuracy(eng):
         got = eng.eval_math(fn, nan_in).cpu().numpy()
         assert np.isnan(got[0]) and got[1] == 1. and got[2] == -1., fn
     assert np.isnan(eng.eval_math('exp', nan_in).cpu().numpy()[0]) and np.all(np.isnan(eng.eval_math('sin', nan_in).cpu().numpy()))
+    got = eng.eval_math('sigmoid', nan_in).cpu().numpy()
+    assert np.isnan(got[0]) and got[1] == 1. and got[2] == 0.
+    got = eng.eval_math('exp', nan_in).cpu().numpy()
+    assert got[1] == np.inf and got[2] == 0.
     # log: the swing-up reward's argument range, the Box-Muller draws' (0, 1], the whole exponent range, and the
     # arguments the fast path hands to the library
     x = np.concatenate([rng.uniform(0.1, 10.2, 20000), 1. - rng.random(20000), 2.**rng.uniform(-1000, 1000, 20000),

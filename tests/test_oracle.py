@@ -446,6 +446,32 @@ def test_oracle_policy_forward_matches_torch():
     np.testing.assert_allclose(orc.policy_forward(ps, params, obs), ref, rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize('nl', ['tanh', 'relu', 'sigmoid', None])
+def test_non_finite_values_pass_the_activations_as_in_torch(nl):
+    """ A NaN weight or observation has to reach the action (rollout() ends on it, sampling/rollout.py:190-201), and an
+    infinite observation saturates tanh and sigmoid: torch.relu keeps a NaN (a comparison-and-select form of relu turns it
+    into 0 and the NaN is lost), tanh(+-inf) = +-1, sigmoid(+-inf) = 1 / 0. """
+    import torch
+    act = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU, 'sigmoid': torch.nn.Sigmoid, None: torch.nn.Identity}[nl]
+    rng = np.random.default_rng(8)
+    ps = PolicySpec('fnn', 3, 2, hidden=[5, 4], hidden_nonlin=[nl, nl])
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), act(), torch.nn.Linear(5, 4), act(), torch.nn.Linear(4, 2)).double()
+    for case in ('finite', 'nan weight', 'nan obs', 'inf obs', '-inf obs'):
+        params, obs = rng.standard_normal(ps.num_param), rng.standard_normal(3)
+        if case == 'nan weight':
+            params[7] = np.nan    # first layer, second unit
+        elif case != 'finite':
+            obs[1] = dict(nan=np.nan, inf=np.inf)[case.split()[0].lstrip('-')]*(-1 if case[0] == '-' else 1)
+        torch.nn.utils.vector_to_parameters(torch.as_tensor(params.copy()), net.parameters())
+        with torch.no_grad():
+            ref = net(torch.as_tensor(obs)).numpy()
+        got = orc.policy_forward(ps, params, obs)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref), err_msg=case)
+        if case in ('nan weight', 'nan obs'):
+            assert np.isnan(ref).all(), case
+        np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-12, atol=1e-13, err_msg=case)
+
+
 # ------------------------------------------------------------------------------------------- golden vectors
 @pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'rollout_*.npz'))), ids=os.path.basename)
 def test_c_oracle_reproduces_golden_vectors(path):
