@@ -1577,6 +1577,10 @@ static __global__ __launch_bounds__(64) void k_fnn_bounds(const double* __restri
 }
 
 // Builds the packed weight image of k_rollout_fnn from the torch-ordered flat parameter vector.
+// The rows that pad a hidden layer to the MFMA tile (units h .. HP - 1) are copies of the layer's unit 0, not zeros: the
+// next layer's weights for them are zero either way, so a padding unit contributes 0 x (a value unit 0 also takes) --
+// whereas a zero ROW would turn an infinite input into 0 x inf = NaN, which the zero weight behind it keeps a NaN, in a
+// network whose real units saturate at +-1 as they do in the reference.
 template <int KIND>
 __global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict__ out, int total, int O, int A, int HP,
                            int K0, int REM, int n_hidden, int h0, int h1, int h2, int h3, int num_param) {
@@ -1597,16 +1601,16 @@ __global__ void k_pack_fnn(const double* __restrict__ params, double* __restrict
             const int f = (idx - off) >> 6, lane = (idx - off) & 63;
             const int t = f / ks, s = f % ks;
             const int row = 16 * t + (lane & 15), col = 4 * s + (lane >> 4);
-            v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
+            v = (col < last) ? params[poff + (row < h ? row : 0) * last + col] : 0.;
             found = true;
         } else if (idx < off + nfrag + nrem) {
             const int j = idx - off - nfrag;
             const int row = j % HP, col = 4 * K0 + j / HP;
-            v = (row < h && col < last) ? params[poff + row * last + col] : 0.;
+            v = (col < last) ? params[poff + (row < h ? row : 0) * last + col] : 0.;
             found = true;
         } else if (idx < off + nfrag + nrem + HP) {
             const int j = idx - off - nfrag - nrem;
-            v = (j < h) ? params[poff + h * last + j] : 0.;
+            v = params[poff + h * last + (j < h ? j : 0)];
             found = true;
         }
         off += nfrag + nrem + HP;

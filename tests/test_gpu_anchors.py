@@ -218,3 +218,27 @@ def test_a_nan_weight_reaches_the_action_through_every_activation(eng, orc, nonl
         np.testing.assert_array_equal(out['status'], ref['status'], err_msg=str(l))
         np.testing.assert_array_equal(out['length'], ref['length'], err_msg=str(l))
         assert np.all(out['ret'] == 0.) and np.isnan(out['act']).all()
+
+
+@pytest.mark.parametrize('kind', [abi.ENV_OMO, abi.ENV_QQ], ids=['omo', 'qq'])
+@pytest.mark.parametrize('nonlin,hidden', [('tanh', (20, 7, 33)), ('sigmoid', (48, 64)), ('tanh', (64, 64))], ids=str)
+def test_an_infinite_observation_saturates_a_network_of_padded_width(eng, orc, kind, nonlin, hidden):
+    """ torch's tanh and sigmoid answer +-inf with +-1 and 1 / 0, so an infinite velocity in the observation still gives a
+    finite action, and the rollout takes the step that turns its state into a NaN.  The rows that pad a layer to the MFMA
+    tile must not make a NaN of that observation (a zero row would: 0 x inf): actions, rewards, lengths and status words as
+    in the oracle, for environments with and without an infinite component side by side in one tile. """
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    n, T = 200, 3
+    case = cases.make_case(kind, n, seed=12, policy='fnn', hidden=hidden, nonlin=nonlin)
+    init = case['init'].copy()
+    vel = S - 1                                   # the last state component is a velocity in both simulations
+    init[vel, 5], init[vel, 70], init[vel, 71], init[vel, 199] = np.inf, -np.inf, np.inf, -np.inf
+    for flags in (abi.F_STOP_ON_DONE, 0):
+        args = (kind, case['dt'], T, case['task_c'], case['ps'], case['params'], init, case['dp'])
+        ref = orc.rollout(*args, record=True, flags=flags)
+        out = {k: v.cpu().numpy() for k, v in eng.rollout(*args, record=True, flags=flags).items()}
+        assert np.isfinite(ref['act'][0, :, [5, 70, 71, 199]]).all() and np.all(ref['length'][[5, 70, 71, 199]] >= 1)
+        np.testing.assert_array_equal(out['length'], ref['length'])
+        np.testing.assert_array_equal(out['status'], ref['status'])
+        for k in ('act', 'rew', 'ret'):
+            assert cases.rel_err(out[k], ref[k]) <= 1e-9, k
