@@ -88,12 +88,12 @@ template <bool STAB> struct EnvQQ {
         const double s2al = 2. * sal * cal;  // sin(2 al)
         const double a = c0 + c1 * (sal * sal), b = c2 * cal, c = c3;
         const double det = a * c - b * b;
-        const double trq = psh_div_by(km * (u - km * thd), Rm, rRm);
+        const double trq = psh_quot_by(km * (u - km * thd), Rm, rRm);
         const double cc0 = c1 * s2al * thd * ald - c2 * sal * ald * ald;
         const double cc1 = -0.5 * c1 * s2al * thd * thd + c4 * sal;
         const double x = trq - Dr * thd - cc0, y = -Dp * ald - cc1;
         const double rdet = psh_rcp_refined(det);  // one reciprocal serves both quotients
-        const double thdd = psh_div_by(c * x - b * y, det, rdet), aldd = psh_div_by(a * y - b * x, det, rdet);
+        const double thdd = psh_quot_by(c * x - b * y, det, rdet), aldd = psh_quot_by(a * y - b * x, det, rdet);
         // "RK4" of the reference: every stage re-evaluates the accelerations at the UN-ADVANCED state
         // (quanser_qube.py:140), so only the velocity rows of k1..k3 differ from k0.
         double kv[4][2];
@@ -139,7 +139,7 @@ template <> struct Env<PSH_ENV_PEND> {
     PSH_DEV void reset(const double* init, int, bool) { s[0] = init[0]; s[1] = init[1]; refresh(); }
     PSH_DEV void observe(double* o) const { o[0] = sth; o[1] = cth; o[2] = s[1]; }
     PSH_DEV void dynamics(double* act, double dt, bool) {  // pendulum.py:49-61
-        const double th_ddot = psh_div_by(act[0] - hmgl * sth - d_pole * s[1], inertia, r_inertia);
+        const double th_ddot = psh_quot_by(act[0] - hmgl * sth - d_pole * s[1], inertia, r_inertia);
         s[1] += th_ddot * dt;
         s[0] += s[1] * dt;
         refresh();
@@ -204,10 +204,10 @@ template <int KIND> struct EnvQCP {
         // 2x2 solve.  The reference goes through LAPACK's pivoted LU; a11 = m_pole + J_eq always dominates
         // a21 = m_pole*l_pole*cos(th) for physical parameters, so the elimination order is the same.
         // (a11 is a constant of the environment: its quotients take the stored reciprocal and one correction step)
-        const double l21 = psh_div_by(a12, a11, r_a11);
+        const double l21 = psh_quot_by(a12, a11, r_a11);
         const double u22 = a22 - l21 * a12;
-        const double x2 = psh_div_moderate(b2 - l21 * b1, u22);
-        const double x1 = psh_div_by(b1 - x2 * a12, a11, r_a11);
+        const double x2 = psh_quot(b2 - l21 * b1, u22);
+        const double x1 = psh_quot_by(b1 - x2 * a12, a11, r_a11);
         s[2] += x1 * dt; s[3] += x2 * dt;
         s[0] += s[2] * dt; s[1] += s[3] * dt;
         refresh();
@@ -286,26 +286,26 @@ template <> struct Env<PSH_ENV_QBB> {
         }
         const double th_x = s[0] + off_x, th_y = s[1] + off_y, x = s[2], y = s[3];
         const double th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
-        const double th_x_ddot = psh_div_by(A_m * act[0] - B_eq_v * th_x_dot, J_eq, r_J_eq);
-        const double th_y_ddot = psh_div_by(A_m * act[1] - B_eq_v * th_y_dot, J_eq, r_J_eq);
+        const double th_x_ddot = psh_quot_by(A_m * act[0] - B_eq_v * th_x_dot, J_eq, r_J_eq);
+        const double th_y_ddot = psh_quot_by(A_m * act[1] - B_eq_v * th_y_dot, J_eq, r_J_eq);
         double sx, cx, sy, cy, sa, ca, sb, cb;
         psh_sincos(th_x, &sx, &cx); psh_sincos(th_y, &sy, &cy);
         psh_sincos(plate[0], &sa, &ca); psh_sincos(plate[1], &sb, &cb);
         const double rca = psh_rcp_refined(ca), rcb = psh_rcp_refined(cb);  // the plate stays far from vertical
-        const double a_dot = psh_div_by(c_kin * th_x_dot * cx, ca, rca);
-        const double b_dot = psh_div_by(c_kin * -th_y_dot * cy, cb, rcb);  // cos(-th_y) = cos(th_y)
+        const double a_dot = psh_quot_by(c_kin * th_x_dot * cx, ca, rca);
+        const double b_dot = psh_quot_by(c_kin * -th_y_dot * cy, cb, rcb);  // cos(-th_y) = cos(th_y)
         const double r2 = r_ball * r_ball;
         double x_ddot, y_ddot;
         if (simplified) {
-            x_ddot = psh_div_by(c_kin * m_ball * g * r2 * sx, zeta, r_zeta);
-            y_ddot = psh_div_by(c_kin * m_ball * g * r2 * sy, zeta, r_zeta);
+            x_ddot = psh_quot_by(c_kin * m_ball * g * r2 * sx, zeta, r_zeta);
+            y_ddot = psh_quot_by(c_kin * m_ball * g * r2 * sy, zeta, r_zeta);
         } else {
             const double a_ddot = rca * (c_kin * (th_x_ddot * cx - (th_x_dot * th_x_dot) * sx) + (a_dot * a_dot) * sa);
             // sin(-th_y) = -sin(th_y)
             const double b_ddot = rcb * (c_kin * (-th_y_ddot * cy - (th_y_dot * th_y_dot) * (-sy)) + (b_dot * b_dot) * sb);
-            x_ddot = psh_div_by(-c_frict * x_dot * r2 - J_ball * r_ball * a_ddot + m_ball * x * (a_dot * a_dot) * r2 +
+            x_ddot = psh_quot_by(-c_frict * x_dot * r2 - J_ball * r_ball * a_ddot + m_ball * x * (a_dot * a_dot) * r2 +
                                 c_kin * m_ball * g * r2 * sx, zeta, r_zeta);
-            y_ddot = psh_div_by(-c_frict * y_dot * r2 - J_ball * r_ball * b_ddot + m_ball * y * (b_dot * b_dot) * r2 +
+            y_ddot = psh_quot_by(-c_frict * y_dot * r2 - J_ball * r_ball * b_ddot + m_ball * y * (b_dot * b_dot) * r2 +
                                 c_kin * m_ball * g * r2 * sy, zeta, r_zeta);
         }
         s[4] += th_x_ddot * dt; s[5] += th_y_ddot * dt; s[6] += x_ddot * dt; s[7] += y_ddot * dt;
@@ -346,8 +346,8 @@ template <> struct Env<PSH_ENV_BOB> {
         double sa, ca;
         psh_sincos(a, &sa, &ca);
         const double zeta_beam = m_ball * (x * x) + J_beam;
-        const double x_ddot = psh_div_by(-c_frict * x_dot + m_ball * x * (a_dot * a_dot) - m_ball * g * sa, zeta_ball, r_zeta_ball);
-        const double a_ddot = psh_div_moderate(act[0] - 2. * m_ball * x * x_dot * a_dot - m_ball * g * ca * x, zeta_beam);
+        const double x_ddot = psh_quot_by(-c_frict * x_dot + m_ball * x * (a_dot * a_dot) - m_ball * g * sa, zeta_ball, r_zeta_ball);
+        const double a_ddot = psh_quot(act[0] - 2. * m_ball * x * x_dot * a_dot - m_ball * g * ca * x, zeta_beam);
         s[2] += x_ddot * dt; s[3] += a_ddot * dt;
         s[0] += s[2] * dt; s[1] += s[3] * dt;
     }

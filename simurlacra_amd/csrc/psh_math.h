@@ -71,6 +71,11 @@ PSH_MATH double psh_div_by(double n, double d, double r) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// The two quotients for the simulations' dynamics: the special cases of IEEE division put back (v_div_fixup_f64: an infinite
+// numerator or divisor, a zero divisor, NaNs), which the residual correction turns into NaN -- inf - inf, 0 x inf.
+PSH_MATH double psh_quot_by(double n, double d, double r) { return __builtin_amdgcn_div_fixup(psh_div_by(n, d, r), d, n); }
+PSH_MATH double psh_quot(double n, double d) { return __builtin_amdgcn_div_fixup(psh_div_moderate(n, d), d, n); }
+
 // The nearest integer to x c for |x c| < 2^31, as a double and as an int: the magic-number addition 1.5 * 2^52 leaves it
 // in the low word of the sum in two's complement (an fma and a subtraction, one rounding, instead of a product, v_rndne
 // and a quarter-rate conversion).

@@ -7,9 +7,8 @@ exploration noise, the stochastic reset, the task (default or custom), and now a
 initial state.  The combinations reach kernel variants that the
 fixed cases of the test suite do not pair up.  Lengths and status words must agree exactly, everything else to 1e-9; a
 larger deviation is printed with the oracle's own response to one-ulp changes of its inputs.
-FUZZ_INF=1 also puts infinities into initial states.  Those are expected to show up as mismatches: the kernels' quotients
-(reciprocal and correction) turn an infinite operand into a NaN where IEEE division keeps an infinity or a zero, so the
-components of the state after such a step -- and with them the NaN bit of the status word -- can differ.
+FUZZ_INF=1 also puts infinities into initial states (the special cases of IEEE division in the dynamics, saturating
+activations on infinite observations).
 Usage: python tools/fuzz_launches.py [trials] [first seed]     (FUZZ_SHOW=1: print the environments that differ;
 FUZZ_SEEDS=a,b,c: these trials only) """
 import copy
