@@ -7,7 +7,8 @@ ObsPartialWrapper), a random LinearPolicy (any of the fusable feature functions,
 or FNNPolicy (random sizes and torch nonlinearities), and runs the same rollout both ways: lengths equal, observations,
 actions and rewards within 1e-9 (or within what a rounding error on the initial state does to the stepwise rollout
 itself).
-Three implementations meet here: the kernels' features, networks and wrappers, torch's, and the host wrappers.
+Every third trial also runs the chain behind DomainRandWrapperLive in a ParallelSampler, fused against the batched step
+loop of a policy that cannot be fused.  Three implementations meet here: the kernels' features, networks and wrappers, torch's, and the host wrappers.
 Usage: python tools/fuzz_host.py [trials] [first seed] """
 import os
 import sys
@@ -84,7 +85,7 @@ def max_dev(a, b):
     return worst
 
 
-bad = fused = skipped = 0
+bad = fused = skipped = samplers = 0
 for trial in range(trials):
     seed = seed0 + trial
     rng = np.random.default_rng(seed)
@@ -164,6 +165,37 @@ for trial in range(trials):
         bad += 0 if explained else 1
         print(f'[{seed}] {"(explained)" if explained else "MISMATCH"} fused={is_fused} lengths {len(ro)} / {len(ref)} dev {dev:.2e}; policy alone '
               f'{pol_dev:.1e}, first steps {head:.1e}, self-sensitivity {sens:.2e} | {what}', flush=True)
+    # The same chain behind DomainRandWrapperLive in a ParallelSampler: the fused batch against the batched reset / step loop
+    # that a policy the kernels cannot fuse takes (the same function, hidden in a plain torch module): the same domain
+    # parameters and initial states are drawn on both paths, so lengths and returns must agree.
+    if stage['stop'] and trial % 3 == 0:
+        try:
+            from simurlacra_amd.domain_randomization import get_default_randomizer
+            from simurlacra_amd.environment_wrappers import DomainRandWrapperLive
+            from simurlacra_amd.sampling import ParallelSampler
+
+            class Opaque(to.nn.Module):
+                def forward(self, obs):
+                    return pol(obs.to(to.float64))
+            n_ro = int(rng.integers(3, 40))
+            envs = [DomainRandWrapperLive(build(rng, stage), get_default_randomizer(build(rng, stage))) for _ in range(2)]
+            a = ParallelSampler(envs[0], pol, 1, min_rollouts=n_ro, seed=seed).sample()
+            b = ParallelSampler(envs[1], Opaque(), 1, min_rollouts=n_ro, seed=seed).sample()
+            la, lb = np.asarray(a.lengths), np.asarray(b.lengths)
+            ra, rb = np.asarray(a.undiscounted_returns()), np.asarray(b.undiscounted_returns())
+            same = la == lb
+            dev_s = float(np.max(np.abs(ra[same] - rb[same])/np.maximum(1., np.abs(rb[same])))) if same.any() else 0.
+            if not same.all() or dev_s > 1e-6:
+                # (closed loops amplify: what counts is a deviation in the FIRST steps of a rollout)
+                k = int(np.flatnonzero(~same)[0]) if not same.all() else int(np.argmax(np.abs(ra - rb)))
+                head = max_dev(a[k][:2], b[k][:2]) if min(la[k], lb[k]) > 2 else 0.
+                ok = head <= 1e-12
+                bad += 0 if ok else 1
+                print(f'[{seed}] sampler {"(explained)" if ok else "MISMATCH"}: {int((~same).sum())} of {n_ro} lengths differ, returns dev {dev_s:.1e}, '
+                      f'first steps of rollout {k}: {head:.1e} | {what}', flush=True)
+            samplers += 1
+        except Exception as ex:
+            print(f'[{seed}] sampler not run ({type(ex).__name__}: {str(ex)[:140]}) | {what}', flush=True)
     if (trial + 1) % 50 == 0:
         print(f'... {trial + 1} trials', flush=True)
-print(f'{trials} trials from seed {seed0}: {bad} unexplained mismatches, {fused} rollouts took the fused kernel, {skipped} chains not built')
+print(f'{trials} trials from seed {seed0}: {bad} unexplained mismatches, {fused} rollouts took the fused kernel, {skipped} chains not built, {samplers} sampler pairs')
