@@ -3,7 +3,8 @@
 a policy (LinearPolicy with plain or structured features, FNNPolicy of random depth / width / nonlinearity), how policies and
 domain parameters are assigned (one policy, an index per environment, a population; a column per environment or an index
 into a few sets), the flags (stop on done, trajectory layout, simplified dynamics), recording on or off, a wrapper chain,
-exploration noise, the stochastic reset, the task (default or custom), and now and then a NaN weight or a NaN in an
+exploration noise, the stochastic reset, the task (default or custom), the entry point (psh_rollout or the
+non-allocating psh_rollout_static), and now and then a NaN weight or a NaN in an
 initial state.  The combinations reach kernel variants that the
 fixed cases of the test suite do not pair up.  Lengths and status words must agree exactly, everything else to 1e-9; a
 larger deviation is printed with the oracle's own response to one-ulp changes of its inputs.
@@ -109,6 +110,7 @@ def draw(rng):
     spec = CUSTOM[kind][rng.integers(len(CUSTOM[kind]))] if t['custom_task'] else cases.envdefs.default_task_spec(kind)
     t['task_c'] = spec.to_c(S, A)
     t['bernoulli'] = 0.02 if rng.random() < 0.15 else 0.
+    t['static'] = bool(rng.random() < 0.15)   # through psh_rollout_static (scratch in the library's static device array)
     return t
 
 
@@ -118,13 +120,14 @@ def describe(t):
     return (f"{cases.KIND_NAMES[t['kind']]:6s} n={t['n']:5d} T={t['T']:3d} {pol} {t['mode']}(pol={t['n_pol']},R={t['R']}) "
             f"dp={'env' if t['dp_index'] is None else t['dp'].shape[1]} flags={t['flags']} rec={int(t['record'])} "
             f"wrap={'-' if t['wrap'] is None else '+'.join(t['wrap'].ops)} expl={ps.expl_kind} bern={t['bernoulli']} "
-            f"task={'custom' if t['custom_task'] else 'default'}")
+            f"task={'custom' if t['custom_task'] else 'default'}{' static' if t.get('static') else ''}")
 
 
 def run(fn, t, init=None, dp=None, to_np=False):
     out = fn(t['kind'], cases.DT[t['kind']], t['T'], t['task_c'], t['ps'], t['params'], t['init'] if init is None else init,
              t['dp'] if dp is None else dp, flags=t['flags'], dp_index=t['dp_index'], policy_index=t['policy_index'],
-             policy_group=t['R'], record=t['record'], wrap=t['wrap'], bernoulli_reset=t['bernoulli'])
+             policy_group=t['R'], record=t['record'], wrap=t['wrap'], bernoulli_reset=t['bernoulli'],
+             **(dict(static_scratch=True) if to_np and t.get('static') else {}))
     if to_np:
         out = {k: v.cpu().numpy() for k, v in out.items()}
         if t['record'] and t['flags'] & abi.F_TRAJ_ENV_MAJOR:   # [N, T(+1), .] -> the oracle's [T(+1), ., N]
@@ -194,7 +197,11 @@ for trial, seed in enumerate(seeds):
                 sens = max(sens, worst_err(ref2, ref, s2, keys))
             except AssertionError:
                 sens = np.inf
-        explained = err <= 100*max(sens, 1e-12) and int((~same).sum()) <= max(2*int((~s2).sum()), 0)
+        # (lengths: an episode that ends on a state bound can end a step earlier or later once a deviation has grown to the
+        # distance from that bound; where one-ulp input changes already move the oracle's own values by 1e-3 and more, a
+        # handful of such episodes among tens of thousands is that growth, not a defect)
+        n_len = int((~same).sum())
+        explained = err <= 100*max(sens, 1e-12) and (n_len <= 2*int((~s2).sum()) or (sens >= 1e-3 and n_len <= 1 + t['n']//10000))
         bad += 0 if explained else 1
         if not explained and os.environ.get('FUZZ_SHOW'):
             show(t, out, ref, keys)
