@@ -826,15 +826,18 @@ def test_nan_actions_are_flagged_not_fatal(eng, orc):
     assert np.all(out['status'].cpu().numpy() & abi.ST_NAN)
 
 
-@pytest.mark.parametrize('kind', [abi.ENV_QQ, abi.ENV_QBB, abi.ENV_OMO])
-@pytest.mark.parametrize('policy', ['identity', 'features', 'fnn'])
+@pytest.mark.parametrize('kind', cases.KINDS, ids=lambda k: cases.KIND_NAMES[k])
+@pytest.mark.parametrize('policy', ['identity', 'features', 'fnn', 'fnn-padded'])
 def test_nan_and_infinite_initial_states(eng, orc, kind, policy):
     """ rollout() tests the observation and the action for NaN (sampling/rollout.py:172-175, 207-210).  The kernels for a
     LinearPolicy on the plain observations leave the first test to the second (a NaN observation makes the action a
     NaN): status, length and the recorded rows must come out as with both tests, for a NaN and for an infinite state
-    component (whose sine is a NaN, or which fails the bounds at the first step), next to rollouts that run. """
-    kw = dict(feats=('identity',)) if policy == 'identity' else (dict() if policy == 'features' else dict(hidden=(64, 64)))
-    case = cases.make_case(kind, 192, seed=40 + kind, policy='fnn' if policy == 'fnn' else 'linear', **kw)
+    component (whose sine is a NaN, or which fails the bounds at the first step), next to rollouts that run.  What an
+    infinite component turns into follows IEEE arithmetic in the reference -- x / inf = 0, inf / x = inf, 0 * inf = NaN in
+    its matrix products, tanh(inf) = 1 -- and decides the NaN bit of the status word: every recorded value has the
+    oracle's NaN and its infinities. """
+    kw = {'identity': dict(feats=('identity',)), 'features': dict(), 'fnn': dict(hidden=(64, 64)), 'fnn-padded': dict(hidden=(20, 7))}[policy]
+    case = cases.make_case(kind, 192, seed=40 + kind, policy='fnn' if policy.startswith('fnn') else 'linear', **kw)
     init = case['init'].copy()
     S = init.shape[0]
     for j in range(0, 192, 3):
@@ -845,13 +848,12 @@ def test_nan_and_infinite_initial_states(eng, orc, kind, policy):
         got = {k: v.cpu().numpy() for k, v in eng.rollout(*args, record=True, flags=flags).items()}
         np.testing.assert_array_equal(got['length'], ref['length'])
         np.testing.assert_array_equal(got['status'], ref['status'])
-        assert (ref['status'] & abi.ST_NAN).any() and (ref['length'] == 25).any()
-        for k in ('act', 'rew', 'ret'):       # NaN where the reference has NaN (0 * inf in its matrix products included)
-            assert cases.rel_err(got[k], ref[k]) <= TOL, k
-        for k in ('obs', 'final_state'):      # what a non-finite state turns into (inf or NaN) depends on the form of the
-            fin = np.isfinite(ref[k])         # dynamics' expressions: finite entries agree, the others are non-finite
-            np.testing.assert_array_equal(np.isfinite(got[k]), fin, err_msg=k)
-            assert np.max(np.abs(got[k][fin] - ref[k][fin])/np.maximum(1., np.abs(ref[k][fin]))) <= TOL, k
+        assert (ref['status'] & abi.ST_NAN).any() and (ref['length'] > 5).any()
+        for k in ('act', 'rew', 'ret', 'obs', 'final_state'):
+            assert cases.rel_err(got[k], ref[k]) <= TOL, k          # (includes the NaN pattern)
+            inf = np.isinf(ref[k])
+            np.testing.assert_array_equal(np.isinf(got[k]), inf, err_msg=k)
+            np.testing.assert_array_equal(got[k][inf], ref[k][inf], err_msg=k)
 
 
 def _ulp_err(got, ref):
