@@ -985,3 +985,63 @@ def test_trajectory_writeback_at_four_times_the_resident_lanes(eng, orc, kind, m
     gbs = (steps*(O + A + 1) + n*O)*8/ms/1e6
     print(f'{cases.KIND_NAMES[kind]}: {steps/n:.1f} steps per episode, {ms:.2f} ms, {gbs:.0f} GB/s of trajectory bytes')
     assert gbs >= min_gbs
+
+
+def test_maximum_sizes_and_one_beyond(eng, orc):
+    """ The limits of the descriptor (PSH_MAX_*): a LinearPolicy with 8 feature functions and 512 feature values, an
+    FNNPolicy of 4 hidden layers of 64 units, an ActDelayWrapper of 32 steps (fixed, and per environment from the domain
+    parameter table) run like any other launch; one beyond each limit is refused with an error, on both sides of the ABI. """
+    from simurlacra_amd.specs import FeatSpec, PolicySpec, WrapSpec
+    from simurlacra_amd.engine import EngineError
+    kind, n, T = abi.ENV_QBB, 500, 40
+    S, O, A, P, _ = abi.ENV_DIMS[kind]
+    rng = np.random.default_rng(2)
+    base = cases.make_case(kind, n, seed=8, policy='linear')
+
+    def check(ps, params, wrap=None, dp=None, tol=TOL):
+        args = (kind, base['dt'], T, base['task_c'], ps, params, base['init'], base['dp'] if dp is None else dp)
+        ref = orc.rollout(*args, record=True, wrap=wrap)
+        out = {k: v.cpu().numpy() for k, v in eng.rollout(*args, record=True, wrap=wrap).items()}
+        np.testing.assert_array_equal(out['length'], ref['length'])
+        np.testing.assert_array_equal(out['status'], ref['status'])
+        for k in ('obs', 'act', 'rew', 'ret'):
+            assert cases.rel_err(out[k], ref[k]) <= tol, k
+
+    # 8 feature functions, 1 + 8 + 8 + 8 + 8 + 1 + 382 + 96 = 512 feature values
+    D, K = 382, 12
+    centers = np.stack([np.linspace(-1.5, 1.5, K) for _ in range(O)], axis=1)
+    feats = ['const', 'identity', 'squared', 'sin', 'cos', FeatSpec('mult', idcs=[0, 3, 5]),
+             FeatSpec('rff', scale=np.sqrt(2./D), freq=rng.standard_normal((D, O)), shift=2*np.pi*rng.random(D)),
+             FeatSpec('rbf', centers=centers, scale=np.full(O, 3.), state_wise=True)]
+    ps = PolicySpec('linear', O, A, feats=feats)
+    assert len(feats) == abi.PSH_MAX_FEATS and ps.num_feat == abi.PSH_MAX_LIN_FEAT
+    check(ps, 0.05*rng.standard_normal(ps.num_param))
+    # the widest and deepest network
+    ps = PolicySpec('fnn', O, A, hidden=[abi.PSH_MAX_WIDTH]*abi.PSH_MAX_HIDDEN, hidden_nonlin=['tanh']*abi.PSH_MAX_HIDDEN)
+    check(ps, 0.15*rng.standard_normal(ps.num_param))
+    # the longest delay, fixed and per environment (0..32, as the extra row of the domain parameter table)
+    lin = PolicySpec('linear', O, A, feats=['identity'])
+    w = 0.3*rng.standard_normal(lin.num_param)
+    check(lin, w, wrap=WrapSpec(ops=['act_delay'], act_delay=abi.PSH_MAX_DELAY))
+    dp = np.vstack([base['dp'], rng.integers(0, abi.PSH_MAX_DELAY + 1, n).astype(float)[None, :]])
+    check(lin, w, wrap=WrapSpec(ops=['act_norm', 'act_delay'], act_delay_row=P), dp=dp)
+    # one beyond
+    for make in (lambda: PolicySpec('fnn', O, A, hidden=[16]*(abi.PSH_MAX_HIDDEN + 1), hidden_nonlin=['tanh']*(abi.PSH_MAX_HIDDEN + 1)),
+                 lambda: PolicySpec('fnn', O, A, hidden=[abi.PSH_MAX_WIDTH + 1], hidden_nonlin=['tanh']),
+                 lambda: PolicySpec('linear', O, A, feats=feats + ['abs']),
+                 lambda: PolicySpec('linear', O, A, feats=feats[:6] + [FeatSpec('rff', scale=1., freq=rng.standard_normal((D + 97, O)), shift=np.zeros(D + 97))])):
+        bad = make()
+        with pytest.raises((ValueError, EngineError)):
+            eng.rollout(kind, base['dt'], T, base['task_c'], bad, np.zeros(bad.num_param), base['init'], base['dp'])
+    with pytest.raises((ValueError, EngineError)):
+        eng.rollout(kind, base['dt'], T, base['task_c'], lin, w, base['init'], base['dp'], wrap=WrapSpec(ops=['act_delay'], act_delay=abi.PSH_MAX_DELAY + 1))
+    # (the library itself refuses what a caller who fills the descriptor by hand gets wrong: a width beyond the limit)
+    good = PolicySpec('fnn', O, A, hidden=[64], hidden_nonlin=['tanh'])
+    class Wide(PolicySpec):
+        def to_c(self, *a, **kw):
+            p = PolicySpec.to_c(self, *a, **kw)
+            p.hidden[0] = abi.PSH_MAX_WIDTH + 1
+            return p
+    wide = Wide('fnn', O, A, hidden=[64], hidden_nonlin=['tanh'])
+    with pytest.raises(EngineError):
+        eng.rollout(kind, base['dt'], T, base['task_c'], wide, np.zeros(good.num_param + 200), base['init'], base['dp'])
