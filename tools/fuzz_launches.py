@@ -9,7 +9,8 @@ initial state.  The combinations reach kernel variants that the
 fixed cases of the test suite do not pair up.  Lengths and status words must agree exactly, everything else to 1e-9; a
 larger deviation is printed with the oracle's own response to one-ulp changes of its inputs.
 FUZZ_INF=1 also puts infinities into initial states (the special cases of IEEE division in the dynamics, saturating
-activations on infinite observations).
+activations on infinite observations).  FUZZ_WILD=1 makes single domain parameters zero, negative, tiny or huge
+(frictionless joints, massless bodies, singular mass matrices).
 Usage: python tools/fuzz_launches.py [trials] [first seed]     (FUZZ_SHOW=1: print the environments that differ;
 FUZZ_SEEDS=a,b,c: these trials only) """
 import copy
@@ -30,6 +31,7 @@ from tests import cases  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 INF = bool(os.environ.get('FUZZ_INF'))
+WILD = bool(os.environ.get('FUZZ_WILD'))
 DRY = bool(os.environ.get('FUZZ_DRY'))   # no GPU: draw the cases and run the oracle only (checks this script)
 eng = None if DRY else get_engine(0)
 TOL = 1e-9
@@ -95,6 +97,10 @@ def draw(rng):
     if rng.random() < 0.08:   # a few initial states with a NaN in them (FUZZ_INF=1: or an infinity, see the docstring)
         for _ in range(int(rng.integers(1, 4))):
             t['init'][rng.integers(t['init'].shape[0]), rng.integers(n)] = rng.choice([np.nan, np.inf, -np.inf] if INF else [np.nan])
+    if WILD and rng.random() < 0.3:   # FUZZ_WILD=1: domain parameters that are zero, negated, tiny or huge in a few columns
+        for _ in range(int(rng.integers(1, 4))):
+            r, c = rng.integers(dp.shape[0]), rng.integers(M)
+            dp[r, c] = [0., -dp[r, c], 1e-12*dp[r, c], 1e12*dp[r, c]][rng.integers(4)]
     if wrap is not None and wrap.act_delay_row >= 0:
         dp = np.vstack([dp, rng.integers(0, 6, M).astype(float)[None, :]])
     t.update(dp=dp, dp_index=dp_index)
