@@ -3,30 +3,20 @@ SimEnv: simulated environments with domain parameters (Pyrado/pyrado/environment
 """
 from abc import abstractmethod
 
-from .base import Env
+from .base import Env, required
+
+
+def _undefined(self, *value):
+    raise NotImplementedError(f'{type(self).__name__}.domain_param')
 
 
 class SimEnv(Env):
-    @property
-    @abstractmethod
-    def init_space(self):
-        raise NotImplementedError
+    """ An environment whose physics parameters can be read and set as a dict, and whose initial states come from a space. """
+    init_space = required('init_space', 'space the initial states are drawn from')
+    domain_param = property(abstractmethod(_undefined), abstractmethod(_undefined), doc='the physics parameters as a dict')
+    supported_domain_param = property(lambda self: self.get_nominal_domain_param().keys())
 
     @classmethod
     @abstractmethod
     def get_nominal_domain_param(cls) -> dict:
-        raise NotImplementedError
-
-    @property
-    def supported_domain_param(self):
-        return self.get_nominal_domain_param().keys()
-
-    @property
-    @abstractmethod
-    def domain_param(self) -> dict:
-        raise NotImplementedError
-
-    @domain_param.setter
-    @abstractmethod
-    def domain_param(self, param: dict):
         raise NotImplementedError

@@ -58,43 +58,33 @@ def all_tasks(task):
         yield task
 
 
+def _hand_down(name: str):
+    """ A method that calls the method of that name on the wrapped task. """
+    def method(self, *args, **kwargs):
+        return getattr(self._wrapped_task, name)(*args, **kwargs)
+    method.__name__ = name
+    return method
+
+
 class TaskWrapper(Task):
+    """ Passes everything on to the task it wraps (:139-223); subclasses change what they are there for -- the final
+    reward, say -- and inherit the rest. """
+
     def __init__(self, wrapped_task: Task):
         if not isinstance(wrapped_task, Task):
             raise TypeErr(given=wrapped_task, expected_type=Task)
         self._wrapped_task = wrapped_task
 
-    @property
-    def env_spec(self):
-        return self._wrapped_task.env_spec
+    wrapped_task = property(lambda self: self._wrapped_task)
+    env_spec = property(lambda self: self._wrapped_task.env_spec)
+    rew_fcn = property(lambda self: self._wrapped_task.rew_fcn)
+    state_des = property(lambda self: self._wrapped_task.state_des,
+                         lambda self, value: setattr(self._wrapped_task, 'state_des', value))
 
-    @property
-    def wrapped_task(self):
-        return self._wrapped_task
-
-    @property
-    def state_des(self):
-        return self._wrapped_task.state_des
-
-    @state_des.setter
-    def state_des(self, state_des):
-        self._wrapped_task.state_des = state_des
-
-    @property
-    def rew_fcn(self):
-        return self._wrapped_task.rew_fcn
-
-    def reset(self, **kwargs):
-        return self._wrapped_task.reset(**kwargs)
+    reset = _hand_down('reset')
+    has_succeeded = _hand_down('has_succeeded')
+    has_failed = _hand_down('has_failed')
+    is_done = _hand_down('is_done')
 
     def step_rew(self, state, act, remaining_steps=None):
         return self._wrapped_task.step_rew(state, act, remaining_steps)
-
-    def has_succeeded(self, state):
-        return self._wrapped_task.has_succeeded(state)
-
-    def has_failed(self, state):
-        return self._wrapped_task.has_failed(state)
-
-    def is_done(self, state):
-        return self._wrapped_task.is_done(state)
