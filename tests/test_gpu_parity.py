@@ -1045,3 +1045,20 @@ def test_maximum_sizes_and_one_beyond(eng, orc):
     wide = Wide('fnn', O, A, hidden=[64], hidden_nonlin=['tanh'])
     with pytest.raises(EngineError):
         eng.rollout(kind, base['dt'], T, base['task_c'], wide, np.zeros(good.num_param + 200), base['init'], base['dp'])
+
+
+def test_randomized_launches(eng):
+    """ A slice of tools/fuzz_launches.py in the suite: 400 launches whose simulation, sizes, policy, assignment of policies
+    and domain parameters, flags, wrapper chain, exploration, task and entry point are drawn at random, with NaN weights,
+    NaN and infinite initial states among them, against the C oracle -- lengths and status words exact, values to 1e-9
+    or within the oracle's own response to one-ulp changes of its inputs. """
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_launches.py')
+    spec = importlib.util.spec_from_file_location('fuzz_launches', path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    lines = []
+    bad, refused = fuzz.main(range(700000, 700400), eng, inf=True, wild=False, log=lambda *a, **k: lines.append(' '.join(map(str, a))))
+    assert bad == 0, '\n'.join(l for l in lines if 'MISMATCH' in l)
+    assert refused < 80    # (an FNNPolicy with an index per environment, ActDelayWrapper through the static entry point)

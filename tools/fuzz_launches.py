@@ -28,12 +28,9 @@ from simurlacra_amd.specs import PolicySpec  # noqa: E402
 from oracle import oracle_lib as orc  # noqa: E402
 from tests import cases  # noqa: E402
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 INF = bool(os.environ.get('FUZZ_INF'))
 WILD = bool(os.environ.get('FUZZ_WILD'))
 DRY = bool(os.environ.get('FUZZ_DRY'))   # no GPU: draw the cases and run the oracle only (checks this script)
-eng = None if DRY else get_engine(0)
 TOL = 1e-9
 SIZES = [1, 3, 16, 17, 63, 64, 65, 100, 257, 1000, 1025, 2049, 4100, 20000, 70001]
 HIDDEN = [(16, 16), (32, 32), (64, 64), (64,), (8,), (20, 7, 33), (64, 64, 64), (48, 64), (64, 17), (5, 5, 5, 5)]
@@ -167,52 +164,65 @@ def worst_err(out, ref, same, keys):
     return max(cases.rel_err(out[k][..., same], ref[k][..., same]) for k in keys)
 
 
-bad = unsupported = 0
-t_start = time.time()
-seeds = [int(x) for x in os.environ['FUZZ_SEEDS'].split(',')] if os.environ.get('FUZZ_SEEDS') else range(seed0, seed0 + trials)
-for trial, seed in enumerate(seeds):
-    rng = np.random.default_rng(seed)
-    t = draw(rng)
-    oflags = t['flags'] & ~abi.F_TRAJ_ENV_MAJOR
-    t_or = dict(t, flags=oflags)
-    try:
-        ref = run(orc.rollout, t_or)
-    except Exception as ex:   # the oracle refuses the combination: not a case
-        unsupported += 1
-        print(f'[{seed}] oracle: {type(ex).__name__}: {ex} | {describe(t)}', flush=True)
-        continue
-    try:
-        out = ref if DRY else run(eng.rollout, t, to_np=True)
-    except Exception as ex:
-        unsupported += 1
-        print(f'[{seed}] engine: {type(ex).__name__}: {str(ex)[:150]} | {describe(t)}', flush=True)
-        continue
-    keys = ['ret', 'final_state'] + (['obs', 'act', 'rew'] if t['record'] else [])
-    same = (out['length'] == ref['length']) & (out['status'] == ref['status'])
-    try:
-        err = worst_err(out, ref, same, keys)
-    except AssertionError as ex:
-        err = np.inf
-        print(f'[{seed}] {ex}', flush=True)
-    if err > TOL or not same.all():
-        sens, s2 = 0., np.ones(t['n'], dtype=bool)
-        for init2, dp2 in ((np.nextafter(t['init'], np.inf), t['dp']), (t['init'], t['dp']*(1 + 2.**-52))):
-            ref2 = run(orc.rollout, t_or, init=init2, dp=dp2)
-            s2 = s2 & (ref2['length'] == ref['length']) & (ref2['status'] == ref['status'])
-            try:
-                sens = max(sens, worst_err(ref2, ref, s2, keys))
-            except AssertionError:
-                sens = np.inf
-        # (lengths: an episode that ends on a state bound can end a step earlier or later once a deviation has grown to the
-        # distance from that bound; where one-ulp input changes already move the oracle's own values by 1e-3 and more, a
-        # handful of such episodes among tens of thousands is that growth, not a defect)
-        n_len = int((~same).sum())
-        explained = err <= 100*max(sens, 1e-12) and (n_len <= 2*int((~s2).sum()) or (sens >= 1e-3 and n_len <= 1 + t['n']//10000))
-        bad += 0 if explained else 1
-        if not explained and os.environ.get('FUZZ_SHOW'):
-            show(t, out, ref, keys)
-        print(f'[{seed}] {"(explained) " if explained else "MISMATCH "}err {err:.2e}, {int((~same).sum())} envs differ in length/status; '
-              f'oracle self-sensitivity {sens:.2e}, {int((~s2).sum())} lengths | {describe(t)}', flush=True)
-    if (trial + 1) % 25 == 0:
-        print(f'... {trial + 1} trials, {time.time() - t_start:.0f} s', flush=True)
-print(f'{trials} trials from seed {seed0}: {bad} unexplained mismatches, {unsupported} combinations refused')
+def main(seeds, eng, inf=None, wild=None, log=print):
+    """ Runs the trials with these seeds on `eng` (None: the oracle against itself); returns the numbers of unexplained
+    mismatches and of refused combinations. """
+    global INF, WILD
+    INF, WILD = (INF if inf is None else inf), (WILD if wild is None else wild)
+    print = log   # noqa: A001
+    bad = unsupported = 0
+    t_start = time.time()
+    for trial, seed in enumerate(seeds):
+        rng = np.random.default_rng(seed)
+        t = draw(rng)
+        oflags = t['flags'] & ~abi.F_TRAJ_ENV_MAJOR
+        t_or = dict(t, flags=oflags)
+        try:
+            ref = run(orc.rollout, t_or)
+        except Exception as ex:   # the oracle refuses the combination: not a case
+            unsupported += 1
+            print(f'[{seed}] oracle: {type(ex).__name__}: {ex} | {describe(t)}', flush=True)
+            continue
+        try:
+            out = ref if eng is None else run(eng.rollout, t, to_np=True)
+        except Exception as ex:
+            unsupported += 1
+            print(f'[{seed}] engine: {type(ex).__name__}: {str(ex)[:150]} | {describe(t)}', flush=True)
+            continue
+        keys = ['ret', 'final_state'] + (['obs', 'act', 'rew'] if t['record'] else [])
+        same = (out['length'] == ref['length']) & (out['status'] == ref['status'])
+        try:
+            err = worst_err(out, ref, same, keys)
+        except AssertionError as ex:
+            err = np.inf
+            print(f'[{seed}] {ex}', flush=True)
+        if err > TOL or not same.all():
+            sens, s2 = 0., np.ones(t['n'], dtype=bool)
+            for init2, dp2 in ((np.nextafter(t['init'], np.inf), t['dp']), (t['init'], t['dp']*(1 + 2.**-52))):
+                ref2 = run(orc.rollout, t_or, init=init2, dp=dp2)
+                s2 = s2 & (ref2['length'] == ref['length']) & (ref2['status'] == ref['status'])
+                try:
+                    sens = max(sens, worst_err(ref2, ref, s2, keys))
+                except AssertionError:
+                    sens = np.inf
+            # (lengths: an episode that ends on a state bound can end a step earlier or later once a deviation has grown to the
+            # distance from that bound; where one-ulp input changes already move the oracle's own values by 1e-3 and more, a
+            # handful of such episodes among tens of thousands is that growth, not a defect)
+            n_len = int((~same).sum())
+            explained = err <= 100*max(sens, 1e-12) and (n_len <= 2*int((~s2).sum()) or (sens >= 1e-3 and n_len <= 1 + t['n']//10000))
+            bad += 0 if explained else 1
+            if not explained and os.environ.get('FUZZ_SHOW'):
+                show(t, out, ref, keys)
+            print(f'[{seed}] {"(explained) " if explained else "MISMATCH "}err {err:.2e}, {int((~same).sum())} envs differ in length/status; '
+                  f'oracle self-sensitivity {sens:.2e}, {int((~s2).sum())} lengths | {describe(t)}', flush=True)
+        if (trial + 1) % 25 == 0:
+            print(f'... {trial + 1} trials, {time.time() - t_start:.0f} s', flush=True)
+    return bad, unsupported
+
+
+if __name__ == '__main__':
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    seeds = [int(x) for x in os.environ['FUZZ_SEEDS'].split(',')] if os.environ.get('FUZZ_SEEDS') else range(seed0, seed0 + trials)
+    bad, unsupported = main(seeds, None if DRY else get_engine(0))
+    print(f'{len(seeds)} trials from seed {seeds[0]}: {bad} unexplained mismatches, {unsupported} combinations refused')
