@@ -1062,3 +1062,17 @@ def test_randomized_launches(eng):
     bad, refused = fuzz.main(range(700000, 700400), eng, inf=True, wild=False, log=lambda *a, **k: lines.append(' '.join(map(str, a))))
     assert bad == 0, '\n'.join(l for l in lines if 'MISMATCH' in l)
     assert refused < 80    # (an FNNPolicy with an index per environment, ActDelayWrapper through the static entry point)
+
+
+def test_randomized_steps_and_sampling(eng):
+    """ A slice of tools/fuzz_steps.py in the suite: psh_reset + psh_step under random actions (outside the bounds, zeros,
+    NaN, past `done`), psh_randomize with random lists of distributions, psh_sample_init, psh_topk with ties and NaNs and
+    psh_segment_mean, 200 trials each, against the C oracle and NumPy. """
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_steps.py')
+    spec = importlib.util.spec_from_file_location('fuzz_steps', path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    lines = []
+    assert fuzz.main(range(800000, 800200), eng, out=lines.append) == 0, '\n'.join(lines)

@@ -20,9 +20,8 @@ from simurlacra_amd.engine import get_engine  # noqa: E402
 from oracle import oracle_lib as orc  # noqa: E402
 from tests import cases  # noqa: E402
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-eng = get_engine(0)
+eng = None     # set by main()
+log = print
 TOL = 1e-9
 CUSTOM = {}
 for kind_, spec_, _ in cases.custom_tasks():
@@ -33,7 +32,7 @@ bad = 0
 def report(seed, what, msg):
     global bad
     bad += 1
-    print(f'[{seed}] {what}: {msg}', flush=True)
+    log(f'[{seed}] {what}: {msg}')
 
 
 def close(a, b, tol=TOL):
@@ -142,13 +141,23 @@ def fuzz_stats(seed, rng):
         report(seed, f'segment_mean g={g}', 'differs')
 
 
-for trial in range(trials):
-    seed = seed0 + trial
-    rng = np.random.default_rng(seed)
-    fuzz_steps(seed, rng)
-    fuzz_randomize(seed, rng)
-    fuzz_sample_init(seed, rng)
-    fuzz_stats(seed, rng)
-    if (trial + 1) % 50 == 0:
-        print(f'... {trial + 1} trials', flush=True)
-print(f'{trials} trials from seed {seed0}: {bad} mismatches')
+def main(seeds, engine, out=print):
+    """ Runs the trials with these seeds on `engine`; returns the number of mismatches. """
+    global eng, log, bad
+    eng, log, bad = engine, out, 0
+    for trial, seed in enumerate(seeds):
+        rng = np.random.default_rng(seed)
+        fuzz_steps(seed, rng)
+        fuzz_randomize(seed, rng)
+        fuzz_sample_init(seed, rng)
+        fuzz_stats(seed, rng)
+        if (trial + 1) % 50 == 0:
+            out(f'... {trial + 1} trials')
+    return bad
+
+
+if __name__ == '__main__':
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    n_bad = main(range(seed0, seed0 + trials), get_engine(0), out=lambda m: print(m, flush=True))
+    print(f'{trials} trials from seed {seed0}: {n_bad} mismatches')
