@@ -556,3 +556,20 @@ def test_device_bootstrap_matches_the_oracle_draws_and_the_host_interval():
         assert abs(m_d - m_h) < 5e-3
         assert ci_d[0] == ci_h[0] == -np.inf or abs(ci_d[0] - ci_h[0]) < tol
         assert abs(ci_d[1] - ci_h[1]) < tol and ci_d[0] < x.mean() < ci_d[1]
+
+
+def test_randomized_rollouts_through_the_host_interface():
+    """ A slice of tools/fuzz_host.py in the suite: 250 random simulations behind random chains of ObsNorm / ActNorm /
+    ActDelay / ObsPartial wrappers in random order, with random LinearPolicy feature stacks and FNNPolicies -- rollout()
+    through the fused kernel against the stepwise loop over the wrapper objects with the policy evaluated by torch, and
+    every third chain behind DomainRandWrapperLive in a ParallelSampler against the batched step loop. """
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_host.py')
+    spec = importlib.util.spec_from_file_location('fuzz_host', path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    lines = []
+    bad, fused, skipped, samplers = fuzz.main(range(900000, 900250), log=lines.append)
+    assert bad == 0, '\n'.join(l for l in lines if 'MISMATCH' in l)
+    assert fused == 250 and skipped == 0 and samplers > 40
