@@ -22,6 +22,11 @@
  *    another stream waits for the previous rollout of the same ctx), so one rollout per ctx runs at a time.
  *  - NaN never aborts a kernel: the per-env `status` word carries PSH_ST_NAN and the host layer raises
  *    the reference's ValueErr (Pyrado/pyrado/sampling/rollout.py:141-147,187-193).
+ *  - Infinite values are not an error in the reference and none here: they go through the dynamics, the rewards and
+ *    the policies as IEEE arithmetic takes them through the reference's NumPy / torch code (x / inf = 0, 0 * inf = NaN
+ *    in a matrix product, tanh(inf) = 1, relu(NaN) = NaN), so an environment whose state has left the finite range ends
+ *    with the status word, length and values the reference computes for it (a finite state beyond 1e154, whose square
+ *    overflows in the reward, excepted: -inf or NaN there depends on the order of the sums).
  */
 #ifndef PYSIMHIP_H
 #define PYSIMHIP_H
