@@ -152,7 +152,9 @@ def main(seeds, log=print):
             # initial state moves by a rounding error.
             with to.no_grad():
                 act_t = np.stack([np.atleast_1d(pol(to.as_tensor(o)).numpy()) for o in ro.observations[:-1]]) if len(ro) else np.zeros((0, 1))
-            pol_dev = float(np.max(np.abs(act_t - ro.actions)/np.maximum(1., np.abs(ro.actions)))) if len(ro) else 0.
+            # (QBallBalancerSim writes its dead zone into the recorded action: those entries are exact zeros, not the policy's output)
+            live = np.asarray(ro.actions) != 0.
+            pol_dev = float(np.max(np.where(live, np.abs(act_t - ro.actions)/np.maximum(1., np.abs(ro.actions)), 0.))) if len(ro) else 0.
             same_len = len(ro) == len(ref)
             head = max_dev(ro[:3], ref[:3]) if same_len and len(ro) > 3 else (dev if same_len else np.inf)
             try:
@@ -162,10 +164,23 @@ def main(seeds, log=print):
                 sens = np.inf if len(ref2) != len(ref) else max_dev(ref2, ref)*(2.**-52/1e-13)
             except Exception:
                 sens = np.inf
-            explained = (pol_dev <= 1e-12 and head <= 1e-12 and sens > 1e-14) or dev <= 100*max(sens, 1e-12)
+            # the environment alone: the fused rollout's recorded actions through the wrapper objects, step by step
+            env_c = build(rng, stage)
+            obs_c = [env_c.reset(init_state=init.copy(), domain_param=dict(dp_dict))]
+            rew_c = []
+            for a_k in np.asarray(ro.actions):
+                o_k, r_k, _, _ = env_c.step(np.array(a_k, dtype=np.float64))
+                obs_c.append(o_k)
+                rew_c.append(r_k)
+            # (rewards only of the steps whose recorded action is the policy's output: where QBallBalancerSim wrote its dead zone
+            # into the action, the step reward was computed from the value before it)
+            whole = np.all(np.asarray(ro.actions) != 0., axis=1)
+            env_dev = max(cases.rel_err(np.asarray(ro.observations), np.stack(obs_c)),
+                          cases.rel_err(np.asarray(ro.rewards)[whole], np.asarray(rew_c)[whole]))
+            explained = (pol_dev <= 1e-12 and head <= 1e-12 and env_dev <= 1e-10) or dev <= 100*max(sens, 1e-12)
             bad += 0 if explained else 1
             print(f'[{seed}] {"(explained)" if explained else "MISMATCH"} fused={is_fused} lengths {len(ro)} / {len(ref)} dev {dev:.2e}; policy alone '
-                  f'{pol_dev:.1e}, first steps {head:.1e}, self-sensitivity {sens:.2e} | {what}', flush=True)
+                  f'{pol_dev:.1e}, environment alone {env_dev:.1e}, first steps {head:.1e}, self-sensitivity {sens:.2e} | {what}', flush=True)
         # The same chain behind DomainRandWrapperLive in a ParallelSampler: the fused batch against the batched reset / step loop
         # that a policy the kernels cannot fuse takes (the same function, hidden in a plain torch module): the same domain
         # parameters and initial states are drawn on both paths, so lengths and returns must agree.
