@@ -12,7 +12,7 @@ FUZZ_INF=1 also puts infinities into initial states (the special cases of IEEE d
 activations on infinite observations).  FUZZ_WILD=1 makes single domain parameters zero, negative, tiny or huge
 (frictionless joints, massless bodies, singular mass matrices).
 Usage: python tools/fuzz_launches.py [trials] [first seed]     (FUZZ_SHOW=1: print the environments that differ;
-FUZZ_SEEDS=a,b,c: these trials only) """
+FUZZ_SEEDS=a,b,c: these trials only; FUZZ_SIZES / FUZZ_HORIZONS: other batch sizes and horizons) """
 import copy
 import dataclasses
 import os
@@ -33,6 +33,11 @@ WILD = bool(os.environ.get('FUZZ_WILD'))
 DRY = bool(os.environ.get('FUZZ_DRY'))   # no GPU: draw the cases and run the oracle only (checks this script)
 TOL = 1e-9
 SIZES = [1, 3, 16, 17, 63, 64, 65, 100, 257, 1000, 1025, 2049, 4100, 20000, 70001]
+HORIZONS = [1, 2, 7, 30, 60, 120, 250]
+if os.environ.get('FUZZ_SIZES'):      # e.g. FUZZ_SIZES=131072,300001 FUZZ_HORIZONS=250,600: few, large launches (queue, drain)
+    SIZES = [int(x) for x in os.environ['FUZZ_SIZES'].split(',')]
+if os.environ.get('FUZZ_HORIZONS'):
+    HORIZONS = [int(x) for x in os.environ['FUZZ_HORIZONS'].split(',')]
 HIDDEN = [(16, 16), (32, 32), (64, 64), (64,), (8,), (20, 7, 33), (64, 64, 64), (48, 64), (64, 17), (5, 5, 5, 5)]
 CUSTOM = {}
 for kind_, spec_, _ in cases.custom_tasks():
@@ -45,7 +50,7 @@ for kind_, wrap_ in cases.WRAP_CASES:
 def draw(rng):
     kind = cases.KINDS[rng.integers(len(cases.KINDS))]
     S, O, A, P, _ = abi.ENV_DIMS[kind]
-    t = dict(kind=kind, T=int(rng.choice([1, 2, 7, 30, 60, 120, 250])), record=bool(rng.random() < 0.6))
+    t = dict(kind=kind, T=int(rng.choice(HORIZONS)), record=bool(rng.random() < (0.6 if max(SIZES) < 100000 else 0.)))
     wrap = None
     if kind in WRAPS and rng.random() < 0.4:
         wrap = copy.deepcopy(WRAPS[kind][rng.integers(len(WRAPS[kind]))])
