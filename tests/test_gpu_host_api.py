@@ -570,6 +570,6 @@ def test_randomized_rollouts_through_the_host_interface():
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     lines = []
-    bad, fused, skipped, samplers = fuzz.main(range(900000, 900250), log=lines.append)
+    bad, fused, skipped, samplers = fuzz.main(range(900000, 900250), log=lines.append, gentle=True)
     assert bad == 0, '\n'.join(l for l in lines if 'MISMATCH' in l)
     assert fused == 250 and skipped == 0 and samplers > 40

@@ -1059,8 +1059,12 @@ def test_randomized_launches(eng):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     lines = []
-    bad, refused = fuzz.main(range(700000, 700400), eng, inf=True, wild=False, log=lambda *a, **k: lines.append(' '.join(map(str, a))))
+    bad, refused = fuzz.main(range(700000, 700400), eng, inf=True, wild=False, gentle=True,
+                            log=lambda *a, **k: lines.append(' '.join(map(str, a))))
+    # (gentle: gains and horizons that keep every closed loop from amplifying rounding differences, so the outcome does not
+    # hinge on the tool's judgement of chaotic cases; the tool itself runs them)
     assert bad == 0, '\n'.join(l for l in lines if 'MISMATCH' in l)
+    assert sum('(explained)' in l for l in lines) <= 3
     assert refused < 80    # (an FNNPolicy with an index per environment, ActDelayWrapper through the static entry point)
 
 
